@@ -1,0 +1,130 @@
+/*
+ * conv3p.h -- C ABI of the MI355X-native conv3p operator pair (libconv3p_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of hkust-vgd/pointwise: the two
+ * TensorFlow custom ops `Conv3p` and `Conv3pGrad` of tf_conv3p.so
+ *   schema      /root/reference/tf_ops/conv3p/register_op.cpp:44-75   (atrous variant)
+ *   CPU kernels /root/reference/tf_ops/conv3p/tf_conv3p_atrous.cpp:401-509, :526-720
+ *   GPU kernels /root/reference/tf_ops/conv3p/tf_conv3p_atrous.cu:541-642, :659-775  (replaced)
+ *   callers     /root/reference/pointcnn2_acsd.py:10-31,
+ *               /root/reference/scene_seg/pointcnn_scene_seg_acsd.py:9-30
+ * A TensorFlow OpKernel shim (integration/tf_conv3p_shim.cc) or
+ * the Python host mirror (pointwise_amd/conv3p_op.py) binds exactly these symbols.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     stated otherwise; all tensors dense row-major, dtype float (f32) or double (f64),
+ *     the two dtypes the reference registers (register_op.cpp:45).
+ *       points  (B, N, 3)            input  (B, N, Cin)
+ *       filter  (fz, fy, fx, Cin, Cout)   weight index (f*Cin + k)*Cout + c,
+ *                                         tap f = (tz*fy + ty)*fx + tx   (.cpp:290, :490)
+ *       output / grad_out (B, N, Cout)    grad_input (B, N, Cin)   grad_filter like filter
+ *   - stride_xyz is a HOST pointer to {sx, sy, sz} (the reference's int32[3] `stride`
+ *     input, read on the host at .cpp:438-440); voxel_size is passed by value (the
+ *     reference's T[1] `voxel_size` input, .cpp:444).  The non-atrous schema
+ *     (register_op.cpp:9-38) is the special case stride = {1,1,1}.
+ *   - outputs are fully overwritten: the library zero-initialises them itself
+ *     (reference: memset at .cpp:451, :580, :590).
+ *   - no allocation, no host synchronisation, no stdout in the hot calls: all scratch
+ *     comes from the caller's `workspace` (size from conv3p_workspace_bytes), and every
+ *     call is ordered on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - every function returns a status code (0 = OK); nothing throws or exits.
+ *     CONV3P_ERR_INVALID_ARGUMENT corresponds to the reference's
+ *     errors::InvalidArgument / OP_REQUIRES failures (.cpp:410-443, :549-585).
+ *   - re-entrant and thread-safe for distinct workspaces.
+ *   - 64-bit sizes internally: every element offset and byte count is size_t.
+ */
+#ifndef CONV3P_H
+#define CONV3P_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONV3P_ABI_VERSION 1
+
+/* status codes */
+#define CONV3P_OK 0
+#define CONV3P_ERR_INVALID_ARGUMENT 1 /* shape / stride / voxel validation failed            */
+#define CONV3P_ERR_WORKSPACE 2        /* workspace NULL, misaligned (256 B) or too small     */
+#define CONV3P_ERR_UNSUPPORTED 3      /* configuration outside what the kernels handle       */
+#define CONV3P_ERR_LAUNCH 4           /* HIP reported an error when launching                */
+#define CONV3P_ERR_NO_DEVICE 5        /* no gfx950-class HIP device visible                  */
+
+/* which op the workspace is for */
+#define CONV3P_PASS_FORWARD 0
+#define CONV3P_PASS_BACKWARD 1
+#define CONV3P_PASS_NEIGHBOR_COUNT 2
+
+/* Bytes of scratch the given op needs for these shapes (elem_bytes = 4 or 8).
+ * Returns 0 for invalid shapes.  Replaces the reference's per-call
+ * OpKernelContext::allocate_temp (tf_conv3p_atrous.cu:97-106, :598-606). */
+size_t conv3p_workspace_bytes(int pass, int elem_bytes, int B, int N, int Cin, int Cout, int fz,
+                              int fy, int fx);
+
+/* Conv3p forward.  Replaces Conv3pOp<Device,T>::Compute
+ * (tf_conv3p_atrous.cpp:401-509 / tf_conv3p_atrous.cu:541-642). */
+int conv3p_forward_f32(const float *points, const float *input, const float *filter,
+                       const int32_t *stride_xyz, float voxel_size, int B, int N, int Cin,
+                       int Cout, int fz, int fy, int fx, float *output, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int conv3p_forward_f64(const double *points, const double *input, const double *filter,
+                       const int32_t *stride_xyz, double voxel_size, int B, int N, int Cin,
+                       int Cout, int fz, int fy, int fx, double *output, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* Conv3pGrad.  Replaces Conv3pGradOp<Device,T>::Compute
+ * (tf_conv3p_atrous.cpp:526-720 / tf_conv3p_atrous.cu:659-775).
+ * Input order follows the op schema (register_op.cpp:63-72): grad_from_next first. */
+int conv3p_backward_f32(const float *grad_out, const float *points, const float *input,
+                        const float *filter, const int32_t *stride_xyz, float voxel_size, int B,
+                        int N, int Cin, int Cout, int fz, int fy, int fx, float *grad_input,
+                        float *grad_filter, void *workspace, size_t workspace_bytes, void *stream);
+int conv3p_backward_f64(const double *grad_out, const double *points, const double *input,
+                        const double *filter, const int32_t *stride_xyz, double voxel_size, int B,
+                        int N, int Cin, int Cout, int fz, int fy, int fx, double *grad_input,
+                        double *grad_filter, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* Per-point, per-tap neighbour populations, int32 (B, N, fz*fy*fx) on the device.
+ * Restates Grid::neighbor_count / kernelBuildNeighborCount
+ * (tf_conv3p_atrous.cpp:306-379 / tf_conv3p_atrous.cu:288-343): the intermediate both
+ * ops normalise by.  Exported so that neighbour / tap decisions can be checked for
+ * exact integer equality against the CPU reference. */
+int conv3p_neighbor_count_f32(const float *points, const int32_t *stride_xyz, float voxel_size,
+                              int B, int N, int fz, int fy, int fx, int32_t *count,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int conv3p_neighbor_count_f64(const double *points, const int32_t *stride_xyz, double voxel_size,
+                              int B, int N, int fz, int fy, int fx, int32_t *count,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* SELU and its derivative, the activation the reference applies after every conv3p
+ * (/root/reference/selu.py:22-26; pointcnn2_acsd.py:49-67).  y may alias x.
+ * conv3p_selu_grad: dx = dy * selu'(x), expressed through the forward OUTPUT y
+ * (selu' = scale for y > 0 [x >= 0 maps to y >= 0], y + scale*alpha otherwise). */
+int conv3p_selu_f32(const float *x, float *y, size_t n, void *stream);
+int conv3p_selu_grad_f32(const float *y, const float *dy, float *dx, size_t n, void *stream);
+int conv3p_selu_f64(const double *x, double *y, size_t n, void *stream);
+int conv3p_selu_grad_f64(const double *y, const double *dy, double *dx, size_t n, void *stream);
+
+/* Kernel-level timing with HIP events recorded on the caller's stream (bench.py uses it
+ * to derive the roofline of the dominant kernel).  Off by default; when enabled every
+ * kernel launch of this library is bracketed by an event pair.  read() synchronises the
+ * recorded events and returns the number of distinct kernel ids; per id: launches and
+ * total milliseconds.  name() gives the kernel-id's label. */
+int conv3p_profile_enable(int on);
+int conv3p_profile_reset(void);
+int conv3p_profile_kinds(void);
+const char *conv3p_profile_name(int kind);
+int conv3p_profile_read(int kind, uint64_t *launches, double *total_ms);
+
+const char *conv3p_status_string(int status);
+int conv3p_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONV3P_H */

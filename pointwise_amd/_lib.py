@@ -1,0 +1,83 @@
+"""ctypes binding of libconv3p_hip.so -- the C ABI declared in include/conv3p.h.
+
+The product path has no CPU fallback: if the library is missing or a symbol is absent this
+module raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libconv3p_hip.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT = 1
+ERR_WORKSPACE = 2
+ERR_UNSUPPORTED = 3
+ERR_LAUNCH = 4
+ERR_NO_DEVICE = 5
+
+PASS_FORWARD = 0
+PASS_BACKWARD = 1
+PASS_NEIGHBOR_COUNT = 2
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_sz = ctypes.c_size_t
+
+# every symbol include/conv3p.h declares: name -> (restype, argtypes)
+def _sig(real):
+    return {
+        "forward": (_i, [_vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+        "backward": (_i, [_vp, _vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+        "neighbor_count": (_i, [_vp, _vp, real, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+        "selu": (_i, [_vp, _vp, _sz, _vp]),
+        "selu_grad": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    }
+
+
+SYMBOLS = {
+    "conv3p_workspace_bytes": (_sz, [_i] * 9),
+    "conv3p_profile_enable": (_i, [_i]),
+    "conv3p_profile_reset": (_i, []),
+    "conv3p_profile_kinds": (_i, []),
+    "conv3p_profile_name": (ctypes.c_char_p, [_i]),
+    "conv3p_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]),
+    "conv3p_status_string": (ctypes.c_char_p, [_i]),
+    "conv3p_abi_version": (_i, []),
+}
+for _sfx, _real in (("f32", ctypes.c_float), ("f64", ctypes.c_double)):
+    for _name, _s in _sig(_real).items():
+        SYMBOLS["conv3p_%s_%s" % (_name, _sfx)] = _s
+
+_LIB = None
+
+
+class Conv3pLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library and bind every declared symbol (raises if anything is missing)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise Conv3pLibraryError(
+            "libconv3p_hip.so not found at %s -- run `python -m pointwise_amd.build` "
+            "(there is no CPU fallback in the product path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise Conv3pLibraryError("libconv3p_hip.so does not export %s" % name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.conv3p_abi_version() != 1:
+        raise Conv3pLibraryError("libconv3p_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def status_string(code):
+    return load().conv3p_status_string(code).decode()

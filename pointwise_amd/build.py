@@ -1,0 +1,50 @@
+"""Build libconv3p_hip.so (the C-ABI library of include/conv3p.h) for gfx950, in-tree.
+
+    python -m pointwise_amd.build            # build if sources are newer than the library
+    python -m pointwise_amd.build --force
+
+hipcc cross-compiles without a GPU.  Flags:
+  -ffp-contract=off       the tap arithmetic must not be contracted (see conv3p_device.hpp);
+                          FMAs in the accumulation loops are written explicitly
+  -munsafe-fp-atomics     hardware float atomics (ds_add_f32 / global_atomic_add_f32) instead of
+                          CAS loops; all buffers are ordinary coarse-grained device memory
+hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt keeps `/` IEEE-exact on the device.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libconv3p_hip.so")
+SOURCES = ["conv3p_abi.hip", "conv3p_kernels.hpp", "conv3p_device.hpp"]
+HEADER = os.path.join(os.path.dirname(HERE), "include", "conv3p.h")
+ARCH = "gfx950"
+
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
+         "-Wall", "-Wextra", "-Wno-unused-parameter"]
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=" + ARCH] + FLAGS + ["-o", LIB, os.path.join(CSRC, "conv3p_abi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + out.stdout + out.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

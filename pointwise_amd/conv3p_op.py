@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's operator interface for the conv3p hot path.
+
+The reference loads tf_conv3p.so with tf.load_op_library and calls
+    conv3p_module.conv3p(points, input, filter, stride, voxel_size)                  -> output
+    conv3p_module.conv3p_grad(grad, points, input, filter, stride, voxel_size)       -> (grad_input, grad_filter)
+(/root/reference/pointcnn2_acsd.py:10-13, :30; op schema tf_ops/conv3p/register_op.cpp:44-75), and wires
+the gradient in Python returning [None, input_grad, filter_grad, None, None] (pointcnn2_acsd.py:15-31).
+
+This module keeps those names, argument order, shapes and error behaviour, with torch tensors standing in
+for TF tensors (torch is only the device-memory / stream plumbing here): every call goes through the C ABI of
+include/conv3p.h into the hand-written gfx950 kernels.  There is no CPU implementation in this package; CPU
+tensors are rejected.
+
+Shape checks mirror the reference's OP_REQUIRES (tf_conv3p_atrous.cpp:410-443, :549-585) and raise
+Conv3pInvalidArgument (the analogue of tensorflow.errors.InvalidArgumentError) with the same messages.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Conv3pInvalidArgument(ValueError):
+    """Analogue of tf.errors.InvalidArgumentError raised by the op's OP_REQUIRES checks."""
+
+
+class Conv3pRuntimeError(RuntimeError):
+    pass
+
+
+_SFX = {torch.float32: ("f32", ctypes.c_float, 4), torch.float64: ("f64", ctypes.c_double, 8)}
+
+# one growing scratch buffer per (device, stream): the caller-owned workspace of the C ABI
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf, stream
+
+
+def _require(cond, msg):
+    if not cond:
+        raise Conv3pInvalidArgument(msg)
+
+
+def _stride_list(stride):
+    if isinstance(stride, torch.Tensor):
+        _require(stride.dim() >= 1 and stride.shape[0] == 3, "Conv3p expects stride tensor to have size 3.")
+        stride = stride.detach().cpu().tolist()   # host-memory input in the TF op (read on the host, .cpp:438-440)
+    stride = [int(s) for s in stride]
+    _require(len(stride) == 3, "Conv3p expects stride tensor to have size 3.")
+    return (ctypes.c_int32 * 3)(*stride)
+
+
+def _voxel_value(voxel_size):
+    if isinstance(voxel_size, torch.Tensor):
+        _require(voxel_size.dim() >= 1 and voxel_size.shape[0] == 1, "Conv3p expects voxel tensor to have dimension 1.")
+        return float(voxel_size.detach().cpu().reshape(-1)[0])
+    if isinstance(voxel_size, (list, tuple)):
+        _require(len(voxel_size) == 1, "Conv3p expects voxel tensor to have dimension 1.")
+        return float(voxel_size[0])
+    return float(voxel_size)
+
+
+def _check_device(*tensors):
+    dev = tensors[0].device
+    if dev.type != "cuda":
+        raise Conv3pRuntimeError("conv3p: tensors must live on a HIP device (no CPU path in pointwise_amd)")
+    for t in tensors:
+        if t.device != dev:
+            raise Conv3pRuntimeError("conv3p: all tensors must be on the same device")
+    return dev
+
+
+def _common_checks(points, input, filter):
+    _require(points.dim() == 3, "Conv3p expects (batch_size, num_points, 3) points shape")
+    _require(points.shape[2] == 3, "Conv3p expects (batch_size, num_points, 3) points shape")
+    _require(input.dim() == 3 and input.shape[0] == points.shape[0],
+             "Conv3p expects points and input tensor to have the same batch size")
+    _require(input.shape[1] == points.shape[1],
+             "Conv3p expects points and input tensor to have the same number of points")
+    _require(filter.dim() == 5, "Conv3p expects [filter_z, filter_y, filter_x, in_channels, out_channels] filter")
+    _require(filter.shape[3] == input.shape[2], "Conv3p expects filter channels to be matched with input channels")
+    dt = points.dtype
+    if dt not in _SFX:
+        raise Conv3pInvalidArgument("Conv3p: T must be float32 or float64")   # Attr T: {float, double}
+    _require(input.dtype == dt and filter.dtype == dt, "Conv3p: points, input and filter must share dtype T")
+
+
+def _call(fn, *args):
+    rc = fn(*args)
+    if rc == _lib.OK:
+        return
+    msg = "conv3p: %s (status %d)" % (_lib.status_string(rc), rc)
+    if rc == _lib.ERR_INVALID_ARGUMENT:
+        raise Conv3pInvalidArgument(msg)
+    raise Conv3pRuntimeError(msg)
+
+
+def conv3p(points, input, filter, stride, voxel_size):
+    """Conv3p forward.  points (B,N,3), input (B,N,Cin), filter (fz,fy,fx,Cin,Cout), stride [sx,sy,sz]
+    (int32[3]), voxel_size T[1] -> output (B,N,Cout).  Mirrors conv3p_module.conv3p
+    (/root/reference/pointcnn2_acsd.py:12-13)."""
+    lib = _lib.load()
+    _common_checks(points, input, filter)
+    dev = _check_device(points, input, filter)
+    sfx, creal, esz = _SFX[points.dtype]
+    s3 = _stride_list(stride)
+    vox = _voxel_value(voxel_size)
+    B, N, _ = points.shape
+    fz, fy, fx, Cin, Cout = filter.shape
+    points, input, filter = points.contiguous(), input.contiguous(), filter.contiguous()
+    out = torch.empty((B, N, Cout), dtype=points.dtype, device=dev)
+    need = lib.conv3p_workspace_bytes(_lib.PASS_FORWARD, esz, B, N, Cin, Cout, fz, fy, fx)
+    with torch.cuda.device(dev):
+        ws, stream = _workspace(dev, need)
+        _call(getattr(lib, "conv3p_forward_" + sfx), points.data_ptr(), input.data_ptr(), filter.data_ptr(),
+              ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx, out.data_ptr(),
+              ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    return out
+
+
+def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size):
+    """Conv3pGrad -> (grad_input, grad_filter).  Mirrors conv3p_module.conv3p_grad
+    (/root/reference/pointcnn2_acsd.py:30; schema register_op.cpp:63-75)."""
+    lib = _lib.load()
+    _common_checks(points, input, filter)
+    dev = _check_device(grad_from_next, points, input, filter)
+    sfx, creal, esz = _SFX[points.dtype]
+    s3 = _stride_list(stride)
+    vox = _voxel_value(voxel_size)
+    B, N, _ = points.shape
+    fz, fy, fx, Cin, Cout = filter.shape
+    _require(grad_from_next.dim() == 3 and grad_from_next.shape[0] == B, "backprop grad tensor has wrong size for dim 0")
+    _require(grad_from_next.shape[1] == N, "backprop grad tensor has wrong size for dim 1")
+    _require(grad_from_next.shape[2] == Cout, "backprop grad tensor has wrong size for dim 2")
+    _require(grad_from_next.dtype == points.dtype, "Conv3pGrad: grad_from_next must have dtype T")
+    grad_from_next = grad_from_next.contiguous()
+    points, input, filter = points.contiguous(), input.contiguous(), filter.contiguous()
+    dx = torch.empty_like(input)
+    dw = torch.empty_like(filter)
+    need = lib.conv3p_workspace_bytes(_lib.PASS_BACKWARD, esz, B, N, Cin, Cout, fz, fy, fx)
+    with torch.cuda.device(dev):
+        ws, stream = _workspace(dev, need)
+        _call(getattr(lib, "conv3p_backward_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
+              input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout,
+              fz, fy, fx, dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    return dx, dw
+
+
+def neighbor_count(points, filter_zyx, stride, voxel_size):
+    """int32 (B, N, fz*fy*fx) per-tap neighbour populations (the op's normaliser), for exact parity checks."""
+    lib = _lib.load()
+    _require(points.dim() == 3 and points.shape[2] == 3, "Conv3p expects (batch_size, num_points, 3) points shape")
+    dev = _check_device(points)
+    if points.dtype not in _SFX:
+        raise Conv3pInvalidArgument("Conv3p: T must be float32 or float64")
+    sfx, creal, esz = _SFX[points.dtype]
+    s3 = _stride_list(stride)
+    vox = _voxel_value(voxel_size)
+    B, N, _ = points.shape
+    fz, fy, fx = [int(v) for v in filter_zyx]
+    points = points.contiguous()
+    cnt = torch.zeros((B, N, fz * fy * fx), dtype=torch.int32, device=dev)
+    need = lib.conv3p_workspace_bytes(_lib.PASS_NEIGHBOR_COUNT, esz, B, N, 0, 0, fz, fy, fx)
+    with torch.cuda.device(dev):
+        ws, stream = _workspace(dev, need)
+        _call(getattr(lib, "conv3p_neighbor_count_" + sfx), points.data_ptr(), ctypes.cast(s3, ctypes.c_void_p),
+              creal(vox), B, N, fz, fy, fx, cnt.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    return cnt
+
+
+def selu(x):
+    """SELU as the reference applies it after each conv3p (/root/reference/selu.py:22-26)."""
+    lib = _lib.load()
+    dev = _check_device(x)
+    sfx = _SFX[x.dtype][0]
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _call(getattr(lib, "conv3p_selu_" + sfx), x.data_ptr(), y.data_ptr(), x.numel(),
+              torch.cuda.current_stream(dev).cuda_stream)
+    return y
+
+
+def selu_grad(y, dy):
+    """dL/dx of SELU given its output y and dL/dy."""
+    lib = _lib.load()
+    dev = _check_device(y, dy)
+    sfx = _SFX[y.dtype][0]
+    y, dy = y.contiguous(), dy.contiguous()
+    dx = torch.empty_like(y)
+    with torch.cuda.device(dev):
+        _call(getattr(lib, "conv3p_selu_grad_" + sfx), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(),
+              torch.cuda.current_stream(dev).cuda_stream)
+    return dx
+
+
+class Conv3pFunction(torch.autograd.Function):
+    """Autograd wiring identical to the reference's @tf.RegisterGradient('Conv3p')
+    (/root/reference/pointcnn2_acsd.py:15-31): gradients [None, input_grad, filter_grad, None, None]."""
+
+    @staticmethod
+    def forward(ctx, points, input, filter, stride, voxel_size):
+        ctx.save_for_backward(points, input, filter)
+        ctx.stride = stride
+        ctx.voxel_size = voxel_size
+        return conv3p(points, input, filter, stride, voxel_size)
+
+    @staticmethod
+    def backward(ctx, grad_from_next_layer):
+        points, input, filter = ctx.saved_tensors
+        input_grad, filter_grad = conv3p_grad(grad_from_next_layer, points, input, filter, ctx.stride,
+                                              ctx.voxel_size)
+        return None, input_grad, filter_grad, None, None
+
+
+def conv3p_autograd(points, input, filter, stride, voxel_size):
+    return Conv3pFunction.apply(points, input, filter, stride, voxel_size)
