@@ -109,6 +109,12 @@ int conv3p_selu_f32(const float *x, float *y, size_t n, void *stream);
 int conv3p_selu_grad_f32(const float *y, const float *dy, float *dx, size_t n, void *stream);
 int conv3p_selu_f64(const double *x, double *y, size_t n, void *stream);
 int conv3p_selu_grad_f64(const double *y, const double *dy, double *dx, size_t n, void *stream);
+/* dx = (dy_a + dy_b) * selu'(y): the gradient join where a layer's activation feeds both the
+ * next conv3p and the feature concat (pointcnn2_acsd.py:49-69). */
+int conv3p_selu_grad_add_f32(const float *y, const float *dy_a, const float *dy_b, float *dx,
+                             size_t n, void *stream);
+int conv3p_selu_grad_add_f64(const double *y, const double *dy_a, const double *dy_b, double *dx,
+                             size_t n, void *stream);
 
 /* Kernel-level timing with HIP events recorded on the caller's stream (bench.py uses it
  * to derive the roofline of the dominant kernel).  Off by default; when enabled every

@@ -32,6 +32,7 @@ def _sig(real):
         "neighbor_count": (_i, [_vp, _vp, real, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
         "selu": (_i, [_vp, _vp, _sz, _vp]),
         "selu_grad": (_i, [_vp, _vp, _vp, _sz, _vp]),
+        "selu_grad_add": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     }
 
 

@@ -110,10 +110,10 @@ def conv3p(points, input, filter, stride, voxel_size):
     (/root/reference/pointcnn2_acsd.py:12-13)."""
     lib = _lib.load()
     _common_checks(points, input, filter)
-    dev = _check_device(points, input, filter)
-    sfx, creal, esz = _SFX[points.dtype]
     s3 = _stride_list(stride)
     vox = _voxel_value(voxel_size)
+    dev = _check_device(points, input, filter)
+    sfx, creal, esz = _SFX[points.dtype]
     B, N, _ = points.shape
     fz, fy, fx, Cin, Cout = filter.shape
     points, input, filter = points.contiguous(), input.contiguous(), filter.contiguous()
@@ -127,13 +127,13 @@ def conv3p(points, input, filter, stride, voxel_size):
     return out
 
 
-def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size):
+def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_filter_out=None):
     """Conv3pGrad -> (grad_input, grad_filter).  Mirrors conv3p_module.conv3p_grad
-    (/root/reference/pointcnn2_acsd.py:30; schema register_op.cpp:63-75)."""
+    (/root/reference/pointcnn2_acsd.py:30; schema register_op.cpp:63-75).
+    grad_filter_out (optional, not in the reference): a contiguous tensor shaped like filter to write
+    grad_filter into, e.g. a view of the fused buffer that is all-reduced across GPUs."""
     lib = _lib.load()
     _common_checks(points, input, filter)
-    dev = _check_device(grad_from_next, points, input, filter)
-    sfx, creal, esz = _SFX[points.dtype]
     s3 = _stride_list(stride)
     vox = _voxel_value(voxel_size)
     B, N, _ = points.shape
@@ -142,10 +142,17 @@ def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size):
     _require(grad_from_next.shape[1] == N, "backprop grad tensor has wrong size for dim 1")
     _require(grad_from_next.shape[2] == Cout, "backprop grad tensor has wrong size for dim 2")
     _require(grad_from_next.dtype == points.dtype, "Conv3pGrad: grad_from_next must have dtype T")
+    dev = _check_device(grad_from_next, points, input, filter)
+    sfx, creal, esz = _SFX[points.dtype]
     grad_from_next = grad_from_next.contiguous()
     points, input, filter = points.contiguous(), input.contiguous(), filter.contiguous()
     dx = torch.empty_like(input)
-    dw = torch.empty_like(filter)
+    if grad_filter_out is None:
+        dw = torch.empty_like(filter)
+    else:
+        dw = grad_filter_out
+        if dw.shape != filter.shape or dw.dtype != filter.dtype or not dw.is_contiguous() or dw.device != dev:
+            raise Conv3pInvalidArgument("grad_filter_out must be a contiguous tensor like filter")
     need = lib.conv3p_workspace_bytes(_lib.PASS_BACKWARD, esz, B, N, Cin, Cout, fz, fy, fx)
     with torch.cuda.device(dev):
         ws, stream = _workspace(dev, need)
@@ -190,16 +197,22 @@ def selu(x):
     return y
 
 
-def selu_grad(y, dy):
-    """dL/dx of SELU given its output y and dL/dy."""
+def selu_grad(y, dy, dy_b=None):
+    """dL/dx of SELU given its output y and dL/dy (= dy, or dy + dy_b when the activation has two consumers)."""
     lib = _lib.load()
     dev = _check_device(y, dy)
     sfx = _SFX[y.dtype][0]
     y, dy = y.contiguous(), dy.contiguous()
     dx = torch.empty_like(y)
     with torch.cuda.device(dev):
-        _call(getattr(lib, "conv3p_selu_grad_" + sfx), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(),
-              torch.cuda.current_stream(dev).cuda_stream)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if dy_b is None:
+            _call(getattr(lib, "conv3p_selu_grad_" + sfx), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(),
+                  stream)
+        else:
+            dy_b = dy_b.contiguous()
+            _call(getattr(lib, "conv3p_selu_grad_add_" + sfx), y.data_ptr(), dy.data_ptr(), dy_b.data_ptr(),
+                  dx.data_ptr(), y.numel(), stream)
     return dx
 
 

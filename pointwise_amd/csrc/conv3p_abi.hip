@@ -342,14 +342,14 @@ template <typename T> int selu_impl(const T *x, T *y, size_t n, void *stream)
     hipLaunchKernelGGL(selu_kernel<T>, dim3(grid), dim3(256), 0, s, x, y, n);
     return hip_ok();
 }
-template <typename T> int selu_grad_impl(const T *y, const T *dy, T *dx, size_t n, void *stream)
+template <typename T> int selu_grad_impl(const T *y, const T *dy, const T *dy_b, T *dx, size_t n, void *stream)
 {
     if (n == 0) return CONV3P_OK;
     if (!y || !dy || !dx) return CONV3P_ERR_INVALID_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(K_SELU_GRAD, s);
     const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(selu_grad_kernel<T>, dim3(grid), dim3(256), 0, s, y, dy, dx, n);
+    hipLaunchKernelGGL(selu_grad_kernel<T>, dim3(grid), dim3(256), 0, s, y, dy, dy_b, dx, n);
     return hip_ok();
 }
 
@@ -419,11 +419,24 @@ int conv3p_selu_f32(const float *x, float *y, size_t n, void *stream) { return s
 int conv3p_selu_f64(const double *x, double *y, size_t n, void *stream) { return selu_impl<double>(x, y, n, stream); }
 int conv3p_selu_grad_f32(const float *y, const float *dy, float *dx, size_t n, void *stream)
 {
-    return selu_grad_impl<float>(y, dy, dx, n, stream);
+    return selu_grad_impl<float>(y, dy, nullptr, dx, n, stream);
 }
 int conv3p_selu_grad_f64(const double *y, const double *dy, double *dx, size_t n, void *stream)
 {
-    return selu_grad_impl<double>(y, dy, dx, n, stream);
+    return selu_grad_impl<double>(y, dy, nullptr, dx, n, stream);
+}
+
+int conv3p_selu_grad_add_f32(const float *y, const float *dy_a, const float *dy_b, float *dx, size_t n,
+                             void *stream)
+{
+    if (n && !dy_b) return CONV3P_ERR_INVALID_ARGUMENT;
+    return selu_grad_impl<float>(y, dy_a, dy_b, dx, n, stream);
+}
+int conv3p_selu_grad_add_f64(const double *y, const double *dy_a, const double *dy_b, double *dx, size_t n,
+                             void *stream)
+{
+    if (n && !dy_b) return CONV3P_ERR_INVALID_ARGUMENT;
+    return selu_grad_impl<double>(y, dy_a, dy_b, dx, n, stream);
 }
 
 int conv3p_profile_enable(int on)

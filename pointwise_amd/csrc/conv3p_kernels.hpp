@@ -367,12 +367,13 @@ __global__ __launch_bounds__(256) void selu_kernel(const T *__restrict__ x, T *_
 }
 template <typename T>
 __global__ __launch_bounds__(256) void selu_grad_kernel(const T *__restrict__ y, const T *__restrict__ dy,
-                                                        T *__restrict__ dx, size_t n)
+                                                        const T *__restrict__ dy_b, T *__restrict__ dx, size_t n)
 {
     const T alpha = (T)SeluConst<T>::alpha, scale = (T)SeluConst<T>::scale;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const T v = y[i];
-        dx[i] = dy[i] * (v >= (T)0 ? scale : v + scale * alpha);
+        const T g = dy_b ? dy[i] + dy_b[i] : dy[i];
+        dx[i] = g * (v >= (T)0 ? scale : v + scale * alpha);
     }
 }
 

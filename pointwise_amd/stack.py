@@ -1,0 +1,93 @@
+"""The conv3p layer stacks of the reference's two models, driven through the operator mirror.
+
+Classification (/root/reference/pointcnn2_acsd.py:48-67):
+    Cin -> 9 (stride 1) -> 9 (stride 2) -> 9 (stride 3) -> 9 (stride 4), SELU after each layer,
+    features = concat of the four activations (36 channels); all layers share `points` and voxel 0.1.
+Segmentation (/root/reference/scene_seg/pointcnn_scene_seg_acsd.py:51-57):
+    the same four layers, then concat(36) -> num_class (stride 1), SELU.
+
+Only the conv3p layers and the SELU between them are here (the hot path of SURVEY.md section 8, row A8);
+the dense head, loss, optimizer and data pipeline of the reference are out of scope.
+forward() keeps the activations; backward() takes dL/d(activation) of every layer that has an external
+consumer (the concat for classification, the logits for segmentation) and returns dL/dinput and the weight
+gradients, written into ONE fused buffer so that data-parallel training needs a single all-reduce.
+"""
+import numpy as np
+import torch
+
+from . import conv3p_op as op
+from . import synth
+
+VOXEL = 0.1                       # tf.constant([0.1]), pointcnn2_acsd.py:46
+CLS_STRIDES = (1, 2, 3, 4)        # pointcnn2_acsd.py:47-65
+HIDDEN = 9
+
+
+class Conv3pStack:
+    def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234):
+        """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers)."""
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.num_class = num_class
+        self.layers = []          # (Cin, Cout, stride)
+        c = in_channels
+        for s in CLS_STRIDES:
+            self.layers.append((c, HIDDEN, s))
+            c = HIDDEN
+        if num_class is not None:
+            self.layers.append((HIDDEN * len(CLS_STRIDES), num_class, 1))
+        npdt = np.float32 if dtype == torch.float32 else np.float64
+        self.filters = [torch.from_numpy(synth.filter_weights(3, 3, 3, ci, co, seed + i, dtype=npdt)).to(self.device)
+                        for i, (ci, co, _) in enumerate(self.layers)]
+        sizes = [f.numel() for f in self.filters]
+        self.fused_grad = torch.zeros(sum(sizes), dtype=dtype, device=self.device)
+        self.grad_views = []
+        o = 0
+        for f, n in zip(self.filters, sizes):
+            self.grad_views.append(self.fused_grad[o:o + n].view(f.shape))
+            o += n
+        self._saved = None
+
+    def forward(self, points, features):
+        acts, x = [], features
+        for li in range(4):
+            _, _, s = self.layers[li]
+            x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL))
+            acts.append(x)
+        concat = None
+        if self.num_class is not None:
+            concat = torch.cat(acts, dim=2)
+            acts.append(op.selu(op.conv3p(points, concat, self.filters[4], (1, 1, 1), VOXEL)))
+        self._saved = (points, features, acts, concat)
+        return acts
+
+    def backward(self, upstream):
+        """upstream: classification -> list of 4 tensors dL/d(act_l) (the slices of dL/dconcat);
+        segmentation -> [dL/dlogits_act].  Returns (dL/dfeatures, fused weight-gradient buffer)."""
+        points, features, acts, concat = self._saved
+        if self.num_class is not None:
+            g = op.selu_grad(acts[4], upstream[0])
+            dconcat, _ = op.conv3p_grad(g, points, concat, self.filters[4], (1, 1, 1), VOXEL,
+                                        grad_filter_out=self.grad_views[4])
+            ext = [dconcat[:, :, HIDDEN * i:HIDDEN * (i + 1)].contiguous() for i in range(4)]
+        else:
+            ext = list(upstream)
+        carry = None
+        for li in (3, 2, 1, 0):
+            _, _, s = self.layers[li]
+            g = op.selu_grad(acts[li], ext[li], carry)
+            x_in = acts[li - 1] if li > 0 else features
+            carry, _ = op.conv3p_grad(g, points, x_in, self.filters[li], (s, s, s), VOXEL,
+                                      grad_filter_out=self.grad_views[li])
+        return carry, self.fused_grad
+
+
+def selu_numpy(x):
+    """CPU SELU for the oracle side of stack comparisons (selu.py:22-26)."""
+    alpha, scale = 1.6732632423543772848170429916717, 1.0507009873554804934193349852946
+    return (scale * np.where(x >= 0, x, alpha * np.expm1(x))).astype(x.dtype)
+
+
+def selu_grad_numpy(y, dy):
+    alpha, scale = 1.6732632423543772848170429916717, 1.0507009873554804934193349852946
+    return (dy * np.where(y >= 0, scale, y + scale * alpha)).astype(y.dtype)

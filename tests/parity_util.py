@@ -28,7 +28,9 @@ def make_case(kind, B, N, Cin, Cout, filter_zyx=(3, 3, 3), seed=0, dtype=np.floa
     elif kind == "identical":
         P = np.full((B, N, 3), 0.25, dtype=np.float32)
     elif kind == "isolated":
-        P = (np.arange(B * N * 3, dtype=np.float64).reshape(B, N, 3) * 7.0).astype(np.float32)
+        i = np.arange(N)
+        P = np.stack([i % 5, (i // 5) % 5, i // 25], axis=1)[None].repeat(B, 0).astype(np.float64) * 0.7
+        P = P.astype(np.float32)   # spacing 0.7 > any tested box half-width: only self-pairs
     else:
         raise ValueError(kind)
     P = P.astype(dtype)

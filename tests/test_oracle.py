@@ -1,0 +1,203 @@
+"""CPU tests of the oracle (not gpu): pinning against the reference Grid and the golden fixtures, the
+independent numpy restatement, and the structural properties the reference algorithm has."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import conv3p_numpy as cn
+from oracle import oracle
+from pointwise_amd import synth
+from tests.parity_util import make_case, rel_err
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+VOX = 0.1
+
+
+def test_golden_fixtures_exist():
+    assert len(GOLDEN) >= 19
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_reproduces_golden(path):
+    """Neighbour lists / taps / counts produced by the REFERENCE Grid (stored in the fixture) must be
+    reproduced exactly, in the reference's visit order; y/dX/dW (oracle regression vectors) bit-for-bit."""
+    g = np.load(path)
+    P, X, W, dY = g["points"], g["input"], g["filter"], g["grad_out"]
+    s, vox = tuple(int(v) for v in g["stride"]), float(g["voxel"])
+    fzyx = W.shape[:3]
+    pos = 0
+    for b in range(P.shape[0]):
+        off, idx, tap = oracle.neighbor_lists(P[b], fzyx, s, vox)
+        n = int(g["ref_pairs_per_cloud"][b])
+        assert np.array_equal(off, g["ref_offsets"][b])
+        assert np.array_equal(idx, g["ref_index"][pos:pos + n])
+        assert np.array_equal(tap, g["ref_tap"][pos:pos + n])
+        pos += n
+    assert np.array_equal(oracle.neighbor_count(P, fzyx, s, vox), g["ref_count"])
+    y = oracle.forward(P, X, W, s, vox)
+    dx, dw = oracle.backward(dY, P, X, W, s, vox)
+    assert np.array_equal(y, g["y"]) and np.array_equal(dx, g["dX"]) and np.array_equal(dw, g["dW"])
+
+
+@pytest.mark.parametrize("kind", ["modelnet", "lattice", "room", "cube", "identical"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("stride", [1, 2, 3, 4])
+def test_oracle_matches_reference_grid_live(kind, dtype, stride):
+    """Fresh seeds against oracle/_ref (the reference Grid compiled in place); skipped where _ref is absent."""
+    if oracle.ref_grid("atrous") is None:
+        pytest.skip("oracle/_ref not built (no /root/reference at build time)")
+    P = make_case(kind, 2, 300, 3, 3, seed=1000 + stride, dtype=dtype)[0]
+    s = (stride, stride, stride)
+    for b in range(P.shape[0]):
+        ours = oracle.neighbor_lists(P[b], (3, 3, 3), s, VOX)
+        ref = oracle.reference_grid_lists(P[b], (3, 3, 3), s, VOX)
+        for a, r in zip(ours, ref[:3]):
+            assert np.array_equal(a, r)
+        assert np.array_equal(oracle.neighbor_count(P[b:b + 1], (3, 3, 3), s, VOX)[0], ref[3])
+
+
+@pytest.mark.parametrize("fzyx,s", [((2, 1, 3), (1, 2, 3)), ((5, 5, 5), (1, 1, 1)), ((2, 2, 2), (1, 1, 1)),
+                                    ((4, 4, 4), (2, 2, 2)), ((1, 1, 1), (1, 1, 1)), ((3, 3, 3), (1, 2, 4))])
+def test_oracle_matches_reference_grid_odd_filters(fzyx, s):
+    if oracle.ref_grid("atrous") is None:
+        pytest.skip("oracle/_ref not built")
+    for kind in ("cube", "lattice"):
+        P = make_case(kind, 1, 250, 3, 3, seed=7, dtype=np.float32)[0]
+        ours = oracle.neighbor_lists(P[0], fzyx, s, VOX)
+        ref = oracle.reference_grid_lists(P[0], fzyx, s, VOX)
+        for a, r in zip(ours, ref[:3]):
+            assert np.array_equal(a, r)
+        assert np.array_equal(oracle.neighbor_count(P, fzyx, s, VOX)[0], ref[3])
+
+
+def test_stride_one_equals_non_atrous_reference():
+    """The non-atrous op (tf_conv3p_grid.cpp) is the stride (1,1,1) case of the atrous one."""
+    if oracle.ref_grid("plain") is None:
+        pytest.skip("oracle/_ref not built")
+    P = make_case("modelnet", 1, 400, 3, 3, seed=3)[0]
+    a = oracle.reference_grid_lists(P[0], (3, 3, 3), (1, 1, 1), VOX, kind="plain")
+    b = oracle.reference_grid_lists(P[0], (3, 3, 3), (1, 1, 1), VOX, kind="atrous")
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ours = oracle.neighbor_lists(P[0], (3, 3, 3), (1, 1, 1), VOX)
+    for x, y in zip(ours, a[:3]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("kind", ["modelnet", "lattice", "room"])
+@pytest.mark.parametrize("cfg", [((3, 3, 3), (1, 1, 1), 3, 9), ((3, 3, 3), (2, 2, 2), 9, 9),
+                                 ((3, 3, 3), (4, 4, 4), 9, 9), ((2, 1, 3), (1, 2, 3), 4, 5),
+                                 ((4, 4, 4), (2, 2, 2), 2, 2)])
+def test_c_oracle_vs_numpy_restatement(kind, cfg):
+    """Two structurally different restatements (grid search in C, brute force in numpy) agree to rounding
+    in float64 -- including on lattice data where forward and backward pair sets differ."""
+    fzyx, s, ci, co = cfg
+    P, X, W, dY = make_case(kind, 2, 200, ci, co, fzyx, seed=11, dtype=np.float64)
+    y, (dx, dw) = oracle.forward(P, X, W, s, VOX), oracle.backward(dY, P, X, W, s, VOX)
+    y2, (dx2, dw2) = cn.forward(P, X, W, s, VOX), cn.backward(dY, P, X, W, s, VOX)
+    assert rel_err(y, y2) < 1e-13 and rel_err(dx, dx2) < 1e-13 and rel_err(dw, dw2) < 1e-13
+
+
+def test_backward_is_adjoint_on_generic_data():
+    """<dY, conv(X, W)> is bilinear in (X, W); on generic data (no point on a tap boundary) the reference
+    backward is its exact adjoint:  <dY, conv(dXdir, W)> = <dX, dXdir>  and  <dY, conv(X, dWdir)> = <dW, dWdir>."""
+    P, X, W, dY = make_case("modelnet", 2, 256, 9, 9, seed=21, dtype=np.float64)
+    s = (2, 2, 2)
+    dx, dw = oracle.backward(dY, P, X, W, s, VOX)
+    rng = np.random.default_rng(5)
+    Xd, Wd = rng.normal(size=X.shape), rng.normal(size=W.shape)
+    lhs_x = float((dY * oracle.forward(P, Xd, W, s, VOX)).sum())
+    lhs_w = float((dY * oracle.forward(P, X, Wd, s, VOX)).sum())
+    assert abs(lhs_x - float((dx * Xd).sum())) < 1e-10 * max(1.0, abs(lhs_x))
+    assert abs(lhs_w - float((dw * Wd).sum())) < 1e-10 * max(1.0, abs(lhs_w))
+
+
+def test_lattice_backward_pair_set_differs_from_forward():
+    """On lattice-aligned clouds the reference backward visits a different pair set from its forward
+    (no inclusion re-test, count==0 skip) -- the oracle must reproduce that."""
+    P = synth.lattice(1, 1024, 4, voxel=VOX, span=8)
+    s = (2, 2, 2)
+    off, idx, tap = oracle.neighbor_lists(P[0], (3, 3, 3), s, VOX)
+    i_of = np.repeat(np.arange(1024), np.diff(off))
+    fwd = set(zip(i_of.tolist(), idx.tolist(), tap.tolist()))          # (centre, neighbour, tap)
+    j, ii, f, cnt = oracle.backward_pairs(P[0], (3, 3, 3), s, VOX)
+    bwd = set(zip(ii.tolist(), j.tolist(), f.tolist()))                # same orientation
+    assert len(bwd - fwd) > 0 and len(fwd - bwd) > 0
+    assert (cnt > 0).all()
+
+
+def test_generic_backward_pair_set_equals_forward():
+    P = synth.uniform_cube(1, 600, 9)
+    for st in (1, 2, 3):
+        s = (st, st, st)
+        off, idx, tap = oracle.neighbor_lists(P[0], (3, 3, 3), s, VOX)
+        i_of = np.repeat(np.arange(600), np.diff(off))
+        fwd = set(zip(i_of.tolist(), idx.tolist(), tap.tolist()))
+        j, ii, f, _ = oracle.backward_pairs(P[0], (3, 3, 3), s, VOX)
+        assert fwd == set(zip(ii.tolist(), j.tolist(), f.tolist()))
+
+
+def test_self_is_centre_tap_for_odd_filters():
+    """Contract item 8: for odd extents every point is its own neighbour in the centre tap."""
+    P = synth.modelnet_like(1, 300, 2)
+    for st in (1, 4):
+        cnt = oracle.neighbor_count(P, (3, 3, 3), (st, st, st), VOX)
+        assert (cnt[0, :, 13] >= 1).all()
+
+
+def test_permutation_equivariance_and_batch_independence():
+    P, X, W, dY = make_case("modelnet", 3, 200, 3, 9, seed=31, dtype=np.float64)
+    s = (1, 1, 1)
+    y = oracle.forward(P, X, W, s, VOX)
+    perm = np.random.default_rng(1).permutation(200)
+    y_p = oracle.forward(P[:, perm], X[:, perm], W, s, VOX)
+    assert rel_err(y_p, y[:, perm]) < 1e-13
+    y_1 = oracle.forward(P[1:2], X[1:2], W, s, VOX)
+    assert np.array_equal(y_1[0], y[1])
+
+
+def test_linearity():
+    P, X, W, dY = make_case("room", 1, 300, 9, 9, seed=41, dtype=np.float64)
+    s = (2, 2, 2)
+    X2 = np.random.default_rng(2).normal(size=X.shape)
+    a = oracle.forward(P, 2.0 * X + X2, W, s, VOX)
+    b = 2.0 * oracle.forward(P, X, W, s, VOX) + oracle.forward(P, X2, W, s, VOX)
+    assert rel_err(a, b) < 1e-13
+
+
+def test_openmp_variant_matches_serial():
+    """Forward and grad_input do not depend on the thread count; grad_filter differs only by the
+    order the per-thread partials are added (.cpp:709-716)."""
+    P, X, W, dY = make_case("modelnet", 8, 256, 9, 9, seed=51)
+    s = (2, 2, 2)
+    y1, y4 = oracle.forward(P, X, W, s, VOX, nthreads=1), oracle.forward(P, X, W, s, VOX, nthreads=4)
+    assert np.array_equal(y1, y4)
+    dx1, dw1 = oracle.backward(dY, P, X, W, s, VOX, nthreads=1)
+    dx4, dw4 = oracle.backward(dY, P, X, W, s, VOX, nthreads=4)
+    assert np.array_equal(dx1, dx4)
+    assert rel_err(dw4, dw1) < 1e-5
+
+
+def test_empty_inputs():
+    W = synth.filter_weights(3, 3, 3, 3, 9, 1)
+    y = oracle.forward(np.zeros((0, 10, 3), np.float32), np.zeros((0, 10, 3), np.float32), W, (1, 1, 1), VOX)
+    assert y.shape == (0, 10, 9)
+    y = oracle.forward(np.zeros((2, 0, 3), np.float32), np.zeros((2, 0, 3), np.float32), W, (1, 1, 1), VOX)
+    assert y.shape == (2, 0, 9)
+    dx, dw = oracle.backward(np.zeros((2, 0, 9), np.float32), np.zeros((2, 0, 3), np.float32),
+                             np.zeros((2, 0, 3), np.float32), W, (1, 1, 1), VOX)
+    assert dx.shape == (2, 0, 3) and not dw.any()
+
+
+def test_neighbour_statistics_match_survey():
+    """Sanity anchor on the statistics SURVEY.md 8(a) measured with the reference Grid on unit-sphere surface
+    clouds of 2048 points (mean neighbours/point 18.5 / 10.7 / 8.1 / 6.6 for stride 1-4)."""
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(1, 2048, 3))
+    v /= np.linalg.norm(v, axis=2, keepdims=True)
+    P = v.astype(np.float32)
+    means = [oracle.neighbor_count(P, (3, 3, 3), (s, s, s), VOX).sum() / 2048 for s in (1, 2, 3, 4)]
+    for got, want in zip(means, (18.5, 10.7, 8.1, 6.6)):
+        assert abs(got - want) / want < 0.1, (means,)
