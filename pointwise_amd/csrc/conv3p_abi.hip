@@ -95,6 +95,10 @@ template <typename T> Stencil<T> make_stencil(const Dims &d, const int32_t *stri
         st.full[a] = (st.ext[a] - 1) * st.step[a] + 1;
         st.half[a] = ((double)st.full[a] * 0.5) * (double)voxel;   // .cpp:240, evaluated in double
         if (st.full[a] > st.maxfull) st.maxfull = st.full[a];
+        st.inv[a] = (float)(1.0 / ((double)st.step[a] * (double)voxel));
+        st.shift[a] = (float)((1.0 - 1.0 / (double)st.step[a]) * 0.5 - 0.5);
+        st.halfw[a] = (float)(0.5 / (double)st.step[a]);
+        st.mmax[a] = (float)(st.ext[a] - 1);
     }
     st.ntap = d.ntap;
     st.voxel = voxel;
@@ -104,7 +108,7 @@ template <typename T> Stencil<T> make_stencil(const Dims &d, const int32_t *stri
 BlockMap make_blockmap(const Dims &d)
 {
     BlockMap m;
-    m.blocks_per_cloud = (d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    m.blocks_per_cloud = d.ntiles;   // one workgroup per query tile
     m.clouds = d.B;
     m.rounds = (d.B + 7) / 8;
     return m;
@@ -131,7 +135,7 @@ template <typename T> Workspace<T> carve(const Dims &d, int pass, void *base)
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
     w.pts = reinterpret_cast<PointRec<T> *>(take(sizeof(PointRec<T>) * (size_t)d.B * d.ntiles * kTile));
     w.boxes = reinterpret_cast<T *>(take(sizeof(T) * (size_t)d.B * d.ntiles * 6));
-    if (pass != CONV3P_PASS_NEIGHBOR_COUNT)
+    if (pass == CONV3P_PASS_BACKWARD)
         w.count = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)d.B * d.N * d.ntap));
     if (pass == CONV3P_PASS_BACKWARD) {
         const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
@@ -170,6 +174,17 @@ template <typename T>
 int run_prep(const T *points, const Dims &d, const Workspace<T> &w, hipStream_t s)
 {
     Scope sc(K_PREP, s);
+    if (d.N <= 16384 && d.N > kTile) {
+        int npad = 128;
+        while (npad < d.N) npad <<= 1;
+        const int threads = npad / 2 < 1024 ? (npad / 2 < 64 ? 64 : npad / 2) : 1024;
+        const size_t lds = (size_t)npad * 8;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(prep_sort_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(prep_sort_kernel<T>, dim3(d.B), dim3(threads), lds, s, points, d.N, d.ntiles, npad,
+                           w.pts, w.boxes);
+        return hip_ok();
+    }
     dim3 grid((d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock, d.B);
     hipLaunchKernelGGL(prep_kernel<T>, grid, dim3(256), 0, s, points, d.N, d.ntiles, w.pts, w.boxes);
     return hip_ok();
@@ -178,8 +193,7 @@ int run_prep(const T *points, const Dims &d, const Workspace<T> &w, hipStream_t 
 template <typename T>
 int run_count(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, int32_t *count, hipStream_t s)
 {
-    const size_t lds = lds_common(st) +
-                       kWavesPerBlock * (a16(sizeof(PointRec<T>) * kTile) + a16((size_t)st.ntap * kCntStride * 4));
+    const size_t lds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16((size_t)kWavesPerBlock * 192 * 4);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_COUNT, s);
@@ -194,16 +208,24 @@ template <typename T, int CI, int CO>
 int launch_forward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, const T *input,
                    const T *filter, T *output, hipStream_t s)
 {
+    const int nwaves = CI > 0 ? kWavesPerBlock : 1;
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    const size_t lds = lds_common(st) + (CI > 0 ? a16(nw * sizeof(T)) : 0) +
-                       kWavesPerBlock * (a16(sizeof(PointRec<T>) * kTile) + a16((size_t)st.ntap * kCntStride * 4));
+    const size_t fixed = lds_common(st) + (CI > 0 ? a16(nw * sizeof(T)) : 0) + a16((size_t)st.ntap * kCntStride * 4) +
+                         a16((size_t)nwaves * 192 * 4) + (CI > 0 ? a16((size_t)nwaves * CO * 64 * sizeof(T)) : 0);
+    // hit-mask slots per wave: enough for every candidate tile if LDS allows, else the tail is re-searched
+    const size_t budget = 64 * 1024;
+    if (fixed > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
+    int cap = (d.ntiles + nwaves - 1) / nwaves;
+    const size_t room = budget > fixed ? (budget - fixed) / ((size_t)nwaves * 64 * 8) : 0;
+    if ((size_t)cap > room) cap = (int)room;
+    const size_t lds = fixed + a16((size_t)nwaves * cap * 64 * 8);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_FORWARD, s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(forward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes,
-                       w.count, input, filter, st, d.N, d.ntiles, d.Cin, d.Cout, bm, output);
+    hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(64 * nwaves), lds, s, w.pts, w.boxes,
+                       input, filter, st, d.N, d.ntiles, d.Cin, d.Cout, cap, bm, output);
     return hip_ok();
 }
 
@@ -211,15 +233,16 @@ template <typename T, int CI, int CO>
 int launch_backward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, const T *grad_out,
                     const T *input, const T *filter, T *grad_input, hipStream_t s)
 {
+    const int nwaves = CI > 0 ? kWavesPerBlock : 1;
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    const size_t lds = lds_common(st) + (CI > 0 ? 2 * a16(nw * sizeof(T)) : 0) +
-                       kWavesPerBlock * a16(sizeof(PointRec<T>) * kTile);
+    const size_t lds = lds_common(st) + (CI > 0 ? 2 * a16(nw * sizeof(T)) : 0) + a16((size_t)nwaves * 192 * 4) +
+                       (CI > 0 ? a16((size_t)nwaves * CI * 64 * sizeof(T)) : 0);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_BACKWARD, s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes,
+    hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(64 * nwaves), lds, s, w.pts, w.boxes,
                        w.count, grad_out, input, filter, st, d.N, d.ntiles, d.Cin, d.Cout, bm, grad_input,
                        w.partials);
     return hip_ok();
@@ -257,7 +280,6 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     TRY(ws_check(ws, ws_bytes, w.bytes));
     const Stencil<T> st = make_stencil<T>(d, stride, voxel);
     TRY(run_prep<T>(points, d, w, s));
-    TRY(run_count<T>(d, st, w, w.count, s));
     if constexpr (sizeof(T) == 4) {
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \

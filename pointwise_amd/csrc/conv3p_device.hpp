@@ -1,24 +1,29 @@
 // conv3p_device.hpp -- gfx950 device code shared by the conv3p kernels.
 //
 // MI355X-first design (NOT a translation of tf_conv3p_atrous.cu, which scans all N
-// candidates per point twice per op, accumulates in global memory and does one global
-// float atomic per (pair, k, c)):
+// candidates per point twice per op with the full tap arithmetic, accumulates in global
+// memory and does one global float atomic per (pair, k, c)):
 //
-//   * a cloud is cut into TILES of 64 points = one wavefront; a prep kernel stores each
-//     point as a 16-byte record {x, y, z, original index} (one coalesced dwordx4 per lane)
-//     and each tile's bounding box;
-//   * a wavefront owns one QUERY tile (lane = centre point).  It first culls CANDIDATE
-//     tiles against the union of its 64 filter boxes (one lane per candidate tile, one
-//     ballot), then for every surviving candidate tile
-//        - loads the tile with one coalesced load per lane and parks it in LDS,
-//        - broadcasts the 64 candidates one by one through v_readlane (SGPR operands) and
-//          runs the reference's inclusive box test on all 64 centres at once, building a
-//          64-bit hit mask per lane,
-//        - walks the set bits: tap index with the reference's exact float arithmetic,
-//          hole test, then the op-specific accumulation.
-//   * tap populations live in LDS, lane-private ([tap][lane], stride 65 words);
+//   * a cloud is cut into TILES of 64 points = one wavefront; a prep kernel orders the
+//     points along a Morton curve, stores each as a 16-byte record {x, y, z, original index}
+//     and stores every tile's bounding box;
+//   * one WORKGROUP owns one QUERY tile (lane = centre point, all waves hold the same 64
+//     centres); its waves split the CANDIDATE tiles that survive a bounding-box cull
+//     against the union of the 64 filter boxes;
+//   * per candidate tile a wave runs a two-stage search:
+//       1. PRE-FILTER (vectorised, fp32, conservative): the tile's coordinates are parked in
+//          LDS as structure-of-arrays and read back with wave-uniform addresses (LDS
+//          broadcast, 4 candidates per ds_read_b128), so each VALU instruction tests one
+//          candidate against all 64 centres.  The filter is the atrous lattice itself: per
+//          axis z = (v - lo)/(step*voxel) + shift, d = z - clamp(round(z), 0, ext-1), accept
+//          iff |d| <= 1/(2*step) + eps -- the box test AND the hole test in 4 VALU per axis,
+//          no integer division, no SALU.  The result is a 64-bit hit mask per lane.
+//       2. EXACT (only on set bits): the reference's own arithmetic -- box edges in double
+//          rounded once, inclusive comparison, IEEE division, truncation, clamp, hole test.
+//          Only this stage decides; stage 1 is a strict superset (eps covers fp32 rounding).
+//   * tap populations live in LDS ([tap][lane], stride 65 words), shared by the workgroup;
 //   * weights are staged in LDS once per workgroup; grad_filter is accumulated in an LDS
-//     copy per workgroup and reduced by a second, deterministic-order kernel.
+//     copy per workgroup and reduced by a second, fixed-order kernel.
 //
 // Exactness: box edges are evaluated in double and rounded once (reference
 // tf_conv3p_atrous.cpp:240-245), the box test is inclusive (:277), taps use IEEE
@@ -58,19 +63,12 @@ template <typename T> struct Stencil {
     int maxfull;     // max(full[a]); row length of the tap lookup table
     T voxel;
     double half[3];  // (double)full * 0.5 * (double)voxel        (.cpp:240)
+    // pre-filter constants (fp32, see scan_tile)
+    float inv[3];    // 1 / (step * voxel)
+    float shift[3];  // (1 - 1/step)/2 - 1/2
+    float halfw[3];  // 1 / (2*step)
+    float mmax[3];   // ext - 1
 };
-
-__device__ __forceinline__ float lane_bcast(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-__device__ __forceinline__ double lane_bcast(double v, int l)
-{
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), l);
-    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
-}
 
 template <typename T> __device__ __forceinline__ T wave_min(T v)
 {
@@ -104,6 +102,8 @@ template <typename T> struct Query {
     T p[3];
     T lo[3], hi[3];     // own filter box                              (.cpp:240-245)
     T ulo[3], uhi[3];   // union of the wave's 64 boxes (wave-uniform)
+    float add[3];       // pre-filter addend: -lo*inv + shift (per lane)
+    float thr[3];       // pre-filter half width incl. rounding slack (wave-uniform)
     int orig;           // original index inside the cloud, -1 for padding lanes
 };
 
@@ -121,6 +121,10 @@ __device__ __forceinline__ void make_query(Query<T> &q, const PointRec<T> &me, c
         q.hi[a] = (T)((double)q.p[a] + st.half[a]);
         q.ulo[a] = wave_min(valid ? q.lo[a] : Limits<T>::inf());
         q.uhi[a] = wave_max(valid ? q.hi[a] : -Limits<T>::inf());
+        q.add[a] = (float)((double)st.shift[a] - (double)q.lo[a] * (double)st.inv[a]);
+        // slack: fp32 rounding of v*inv + add at the magnitude of the coordinates involved
+        const float mag = fmaxf(fabsf((float)q.ulo[a]), fabsf((float)q.uhi[a])) * st.inv[a];
+        q.thr[a] = st.halfw[a] + 1.0e-5f + 1.0e-6f * mag;
     }
 }
 
@@ -144,69 +148,148 @@ __device__ __forceinline__ int axis_tap(T v, T lo, T voxel, int full, const int1
 {
     int t = (int)((v - lo) / voxel);
     t = t > full - 1 ? full - 1 : t;
-    if (t < 0) return -1;   // unreachable for finite data (v >= lo up to rounding truncates to 0)
+    t = t < 0 ? 0 : t;   // unreachable for finite data: v >= lo up to rounding truncates to 0 already
     return map_row[t];
 }
 
-// Visit every candidate whose position lies inside the lane's filter box
-// (inclusive test, .cpp:277).  `tile_lds` is this wave's private 64-record LDS slot.
-// on_hit(const PointRec<T>&) runs with only the hit lanes active.
-template <typename T, class OnHit>
-__device__ __forceinline__ void for_each_box_hit(const PointRec<T> *__restrict__ cloud_pts,
-                                                 const T *__restrict__ cloud_box, int ntiles,
-                                                 const Query<T> &q, PointRec<T> *tile_lds,
-                                                 OnHit &&on_hit)
+// Exact membership + tap of candidate v for the lane's query: the reference's inclusive box
+// test (.cpp:277) followed by the tap computation (.cpp:280-290).  Returns the tap or -1.
+template <typename T>
+__device__ __forceinline__ int exact_tap(const PointRec<T> &v, const Query<T> &q, const Stencil<T> &st,
+                                         const int16_t *tapmap)
+{
+    const bool out = (v.x < q.lo[0]) | (v.x > q.hi[0]) | (v.y < q.lo[1]) | (v.y > q.hi[1]) |
+                     (v.z < q.lo[2]) | (v.z > q.hi[2]);
+    if (out) return -1;
+    const int tx = axis_tap(v.x, q.lo[0], st.voxel, st.full[0], tapmap);
+    const int ty = axis_tap(v.y, q.lo[1], st.voxel, st.full[1], tapmap + st.maxfull);
+    const int tz = axis_tap(v.z, q.lo[2], st.voxel, st.full[2], tapmap + 2 * st.maxfull);
+    if ((tx | ty | tz) < 0) return -1;                       // hole (.cpp:285)
+    return (tz * st.ext[1] + ty) * st.ext[0] + tx;           // .cpp:290
+}
+
+// Stage one candidate tile for the pre-filter: lane l writes its point's fp32 coordinates to the
+// wave's SoA slot (soa[0..63] = x, [64..127] = y, [128..191] = z).
+template <typename T>
+__device__ __forceinline__ void stage_tile(float *soa, const PointRec<T> &cand)
 {
     const int lane = threadIdx.x & 63;
-    const bool qvalid = q.orig >= 0;
-    for (int base = 0; base < ntiles; base += 64) {
-        const int t = base + lane;
-        bool ov = false;
-        if (t < ntiles) {
-            const T *bb = cloud_box + (size_t)t * 6;   // {min xyz, max xyz}
-            ov = !(bb[3] < q.ulo[0] || bb[0] > q.uhi[0] || bb[4] < q.ulo[1] || bb[1] > q.uhi[1] ||
-                   bb[5] < q.ulo[2] || bb[2] > q.uhi[2]);
-        }
-        uint64_t tiles = __ballot(ov);
-        while (tiles) {
-            const int ct = base + __builtin_ctzll(tiles);
-            tiles &= tiles - 1;
-            const PointRec<T> cand = cloud_pts[(size_t)ct * kTile + lane];
-            tile_lds[lane] = cand;
-            uint32_t mlo = 0, mhi = 0;
+    soa[lane] = (float)cand.x;
+    soa[64 + lane] = (float)cand.y;
+    soa[128 + lane] = (float)cand.z;
+}
+
+// Pre-filter of the 64 staged candidates against the lane's query.  Candidate c ends up in bit
+// (31 - c) of m0 for c < 32 and bit (63 - c) of m1 otherwise.
+template <typename T>
+__device__ __forceinline__ void scan_tile(const float *soa, const Query<T> &q, const Stencil<T> &st,
+                                          uint32_t &m0, uint32_t &m1)
+{
+    m0 = 0;
+    m1 = 0;
+    const float4 *sx = reinterpret_cast<const float4 *>(soa);
+    const float4 *sy = reinterpret_cast<const float4 *>(soa + 64);
+    const float4 *sz = reinterpret_cast<const float4 *>(soa + 128);
 #pragma unroll
-            for (int c = 0; c < 64; ++c) {
-                const T vx = lane_bcast(cand.x, c);
-                const T vy = lane_bcast(cand.y, c);
-                const T vz = lane_bcast(cand.z, c);
-                const bool out = (vx < q.lo[0]) | (vx > q.hi[0]) | (vy < q.lo[1]) |
-                                 (vy > q.hi[1]) | (vz < q.lo[2]) | (vz > q.hi[2]);
-                if (c < 32)
-                    mlo |= out ? 0u : (1u << c);
-                else
-                    mhi |= out ? 0u : (1u << (c - 32));
-            }
-            uint64_t mask = qvalid ? (((uint64_t)mhi << 32) | mlo) : 0ull;
-            __builtin_amdgcn_wave_barrier();
-            while (__any(mask != 0)) {
-                if (mask != 0) {
-                    const int c = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const PointRec<T> v = tile_lds[c];
-                    on_hit(v);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+    for (int c4 = 0; c4 < 16; ++c4) {
+        const float4 X = sx[c4], Y = sy[c4], Z = sz[c4];   // wave-uniform address: LDS broadcast
+        const float vx[4] = {X.x, X.y, X.z, X.w}, vy[4] = {Y.x, Y.y, Y.z, Y.w}, vz[4] = {Z.x, Z.y, Z.z, Z.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float zx = __builtin_fmaf(vx[u], st.inv[0], q.add[0]);
+            const float zy = __builtin_fmaf(vy[u], st.inv[1], q.add[1]);
+            const float zz = __builtin_fmaf(vz[u], st.inv[2], q.add[2]);
+            const float dx = zx - __builtin_amdgcn_fmed3f(__builtin_rintf(zx), 0.0f, st.mmax[0]);
+            const float dy = zy - __builtin_amdgcn_fmed3f(__builtin_rintf(zy), 0.0f, st.mmax[1]);
+            const float dz = zz - __builtin_amdgcn_fmed3f(__builtin_rintf(zz), 0.0f, st.mmax[2]);
+            const float e = fmaxf(fmaxf(fabsf(dx) - q.thr[0], fabsf(dy) - q.thr[1]), fabsf(dz) - q.thr[2]);
+            const uint32_t bit = e <= 0.0f ? 1u : 0u;
+            if (c4 < 8)
+                m0 = (m0 << 1) | bit;
+            else
+                m1 = (m1 << 1) | bit;
         }
     }
 }
 
-// (cloud, first query tile) of a workgroup.  Workgroup b is placed on XCD b % 8 by the
-// dispatcher (observed, used for L2 locality only): clouds are dealt to XCDs round-robin
-// and all tiles of a cloud run on that cloud's XCD, so points / features / counts of a
-// cloud stay in one XCD's 4 MiB L2.
+// Candidate tiles whose bounding box meets the union of the wave's filter boxes: 64 tiles per
+// ballot, one lane per tile.
+template <typename T>
+__device__ __forceinline__ uint64_t overlapping_tiles(const T *__restrict__ cloud_box, int ntiles, int base,
+                                                      const Query<T> &q)
+{
+    const int t = base + (threadIdx.x & 63);
+    bool ov = false;
+    if (t < ntiles) {
+        const T *bb = cloud_box + (size_t)t * 6;   // {min xyz, max xyz}
+        const T b0 = bb[0], b1 = bb[1], b2 = bb[2], b3 = bb[3], b4 = bb[4], b5 = bb[5];
+        ov = !((b3 < q.ulo[0]) | (b0 > q.uhi[0]) | (b4 < q.ulo[1]) | (b1 > q.uhi[1]) | (b5 < q.ulo[2]) |
+               (b2 > q.uhi[2]));
+    }
+    return __ballot(ov);
+}
+
+// Walk the set bits of a lane's 64-bit hit mask (m0: candidates 0..31, m1: 32..63, see scan_tile).
+// visit(c) runs with only the lanes that still have a candidate active.
+template <class Visit>
+__device__ __forceinline__ void for_each_bit(uint32_t m0, uint32_t m1, Visit &&visit)
+{
+    while (__any(m0 != 0)) {
+        if (m0 != 0) {
+            const int p = __builtin_ctz(m0);
+            m0 &= m0 - 1;
+            visit(31 - p);
+        }
+    }
+    while (__any(m1 != 0)) {
+        if (m1 != 0) {
+            const int p = __builtin_ctz(m1);
+            m1 &= m1 - 1;
+            visit(63 - p);
+        }
+    }
+}
+
+// Search of one query tile by one wave: candidate tiles `first, first+stride, ...` of the
+// surviving list (stride a power of two).  on_hit(const PointRec<T>&, int tap) is called for every EXACT neighbour.
+template <typename T, class OnHit>
+__device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict__ cloud_pts,
+                                                  const T *__restrict__ cloud_box, int ntiles,
+                                                  const Query<T> &q, const Stencil<T> &st,
+                                                  const int16_t *tapmap, float *soa, int first, int stride,
+                                                  OnHit &&on_hit)
+{
+    const int lane = threadIdx.x & 63;
+    const bool qvalid = q.orig >= 0;
+    int seen = 0;
+    for (int base = 0; base < ntiles; base += 64) {
+        uint64_t tiles = overlapping_tiles(cloud_box, ntiles, base, q);
+        while (tiles) {
+            const int ct = base + __builtin_ctzll(tiles);
+            tiles &= tiles - 1;
+            if ((seen++ & (stride - 1)) != first) continue;   // stride is a power of two
+            const PointRec<T> *tile = cloud_pts + (size_t)ct * kTile;
+            stage_tile(soa, tile[lane]);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t m0, m1;
+            scan_tile(soa, q, st, m0, m1);
+            __builtin_amdgcn_wave_barrier();
+            if (!qvalid) m0 = m1 = 0;
+            for_each_bit(m0, m1, [&](int c) {
+                const PointRec<T> v = tile[c];
+                const int f = exact_tap(v, q, st, tapmap);
+                if (f >= 0) on_hit(v, f);
+            });
+        }
+    }
+}
+
+// (cloud, query tile) of a workgroup.  Workgroup b is placed on XCD b % 8 by the dispatcher
+// (observed, used for L2 locality only): clouds are dealt to XCDs round-robin and all tiles of
+// a cloud run on that cloud's XCD, so points / features / counts of a cloud stay in one XCD's
+// 4 MiB L2.
 struct BlockMap {
-    int blocks_per_cloud;   // ceil(ntiles / kWavesPerBlock)
+    int blocks_per_cloud;   // query tiles (or groups of them) per cloud
     int clouds;             // B
     int rounds;             // ceil(B / 8)
 };

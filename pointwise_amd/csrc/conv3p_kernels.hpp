@@ -50,12 +50,140 @@ __global__ __launch_bounds__(256) void prep_kernel(const T *__restrict__ points,
     }
 }
 
+// ---------------------------------------------------------------------------------
+// prep with spatial sort: one workgroup per cloud.  Points are ordered by the Morton code of
+// their position inside the cloud's bounding cube (10 bits per axis), sorted in LDS with a
+// bitonic network on 64-bit (code << 32 | index) keys, then staged as records; every run of 64
+// sorted points is a tile with a tight bounding box, which is what makes the candidate-tile
+// culling of for_each_box_hit effective.  The order only affects speed: neighbour decisions
+// are taken per pair with the reference's arithmetic, whatever the tiling.
+// Requires npad (power of two >= N) * 8 bytes of LDS: N <= 16384.  Larger clouds use
+// prep_kernel (identity order).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ points, int N, int ntiles,
+                                                         int npad, PointRec<T> *__restrict__ pts,
+                                                         T *__restrict__ boxes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    __shared__ float red[6][16];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const T *cloud = points + (size_t)b * N * 3;
+
+    // bounding cube (float precision is enough: the order is a performance hint only)
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = tid; i < N; i += nthr)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = (float)cloud[(size_t)i * 3 + a];
+            mn[a] = v < mn[a] ? v : mn[a];
+            mx[a] = v > mx[a] ? v : mx[a];
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = wave_min(mn[a]);
+        mx[a] = wave_max(mx[a]);
+        if (lane == 0) {
+            red[a][wave] = mn[a];
+            red[3 + a][wave] = mx[a];
+        }
+    }
+    __syncthreads();
+    const int nwaves = nthr >> 6;
+    float ext = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float lo = red[a][0], hi = red[3 + a][0];
+        for (int w = 1; w < nwaves; ++w) {
+            lo = red[a][w] < lo ? red[a][w] : lo;
+            hi = red[3 + a][w] > hi ? red[3 + a][w] : hi;
+        }
+        mn[a] = lo;
+        ext = (hi - lo) > ext ? (hi - lo) : ext;
+    }
+    const float scale = ext > 0.f ? 1023.0f / ext : 0.f;
+
+    for (int i = tid; i < npad; i += nthr) {
+        uint64_t k = ~0ull;   // padding sorts last
+        if (i < N) {
+            uint32_t q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float f = ((float)cloud[(size_t)i * 3 + a] - mn[a]) * scale;
+                f = f < 0.f ? 0.f : (f > 1023.f ? 1023.f : f);
+                q[a] = (uint32_t)f;
+            }
+            const uint32_t code = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+            k = ((uint64_t)code << 32) | (uint32_t)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (npad >> 1); t += nthr) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const uint64_t a = keys[i], c = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > c) == up) {
+                    keys[i] = c;
+                    keys[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+
+    const T inf = Limits<T>::inf();
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int p = tile * kTile + lane;
+        PointRec<T> r;
+        const bool v = p < N;
+        if (v) {
+            const int i = (int)(uint32_t)keys[p];
+            r.x = cloud[(size_t)i * 3 + 0];
+            r.y = cloud[(size_t)i * 3 + 1];
+            r.z = cloud[(size_t)i * 3 + 2];
+            r.idx = i;
+        } else {
+            r.x = r.y = r.z = inf;
+            r.idx = -1;
+        }
+        pts[((size_t)b * ntiles + tile) * kTile + lane] = r;
+        T bmn[3] = {wave_min(v ? r.x : inf), wave_min(v ? r.y : inf), wave_min(v ? r.z : inf)};
+        T bmx[3] = {wave_max(v ? r.x : -inf), wave_max(v ? r.y : -inf), wave_max(v ? r.z : -inf)};
+        if (lane == 0) {
+            T *bb = boxes + ((size_t)b * ntiles + tile) * 6;
+            bb[0] = bmn[0]; bb[1] = bmn[1]; bb[2] = bmn[2];
+            bb[3] = bmx[0]; bb[4] = bmx[1]; bb[5] = bmx[2];
+        }
+    }
+}
+
 // LDS carve helpers (all offsets multiples of 16 B; one extern array per kernel).
 __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// Workgroup geometry: WAVES waves share one query tile and split its candidate tiles.
+// WAVES = 4 for the register-resident ("small") paths; WAVES = 1 for the generic channel
+// path, whose output rows are accumulated in global memory and must have a single owner.
+
 // ---------------------------------------------------------------------------------
 // count: count[(b*N + i)*F + f] = neighbours of i in tap f   (.cpp:306-379)
-// LDS: tapmap | per wave { tile records | [F][65] u32 }
+// LDS: tapmap | [F][65] u32 (shared by the workgroup, ds_add) | per wave SoA slot
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void count_kernel(const PointRec<T> *__restrict__ pts,
@@ -65,38 +193,28 @@ __global__ __launch_bounds__(256) void count_kernel(const PointRec<T> *__restric
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
-    const size_t per_wave = align16(sizeof(PointRec<T>) * kTile) + align16((size_t)st.ntap * kCntStride * 4);
-    char *wave_base = smem + align16((size_t)3 * st.maxfull * 2) + per_wave * (threadIdx.x >> 6);
-    PointRec<T> *tile_lds = reinterpret_cast<PointRec<T> *>(wave_base);
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(wave_base + align16(sizeof(PointRec<T>) * kTile));
+    size_t off = align16((size_t)3 * st.maxfull * 2);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
+    off += align16((size_t)st.ntap * kCntStride * 4);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
+    for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
     __syncthreads();
 
-    int b, blk;
-    if (!block_to_cloud(bm, b, blk)) return;
-    const int lane = threadIdx.x & 63;
-    const int qt = blk * kWavesPerBlock + (threadIdx.x >> 6);
-    if (qt >= ntiles) return;
-
+    int b, qt;
+    if (!block_to_cloud(bm, b, qt)) return;
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
     const T *cloud_box = boxes + (size_t)b * ntiles * 6;
     Query<T> q;
     make_query(q, cloud_pts[(size_t)qt * kTile + lane], st);
-    for (int f = 0; f < st.ntap; ++f) cnt[f * kCntStride + lane] = 0;
 
-    for_each_box_hit(cloud_pts, cloud_box, ntiles, q, tile_lds, [&](const PointRec<T> &v) {
-        const int tx = axis_tap(v.x, q.lo[0], st.voxel, st.full[0], tapmap);
-        const int ty = axis_tap(v.y, q.lo[1], st.voxel, st.full[1], tapmap + st.maxfull);
-        const int tz = axis_tap(v.z, q.lo[2], st.voxel, st.full[2], tapmap + 2 * st.maxfull);
-        if ((tx | ty | tz) >= 0) {
-            const int f = (tz * st.ext[1] + ty) * st.ext[0] + tx;
-            cnt[f * kCntStride + lane] += 1;
-        }
-    });
-    __builtin_amdgcn_wave_barrier();
-    // row-wise write-out: lanes = taps, one query per step (coalesced F*4-byte rows)
-    for (int qq = 0; qq < kTile; ++qq) {
+    for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
+                      [&](const PointRec<T> &, int f) { atomicAdd(&cnt[f * kCntStride + lane], 1u); });
+    __syncthreads();
+    // row-wise write-out: lanes = taps, waves take every 4th query (coalesced F*4-byte rows)
+    for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
         const int orig = __shfl(q.orig, qq);
         if (orig < 0) continue;
         int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
@@ -105,71 +223,98 @@ __global__ __launch_bounds__(256) void count_kernel(const PointRec<T> *__restric
 }
 
 // ---------------------------------------------------------------------------------
-// forward.  CIN/COUT > 0: channel counts are compile-time, the output row lives in
-// registers and the filter in LDS.  CIN == 0: generic shapes -- the output row is
-// accumulated in (pre-zeroed) global memory, owned by the lane, filter read through L1/L2.
-// LDS: tapmap | filter (small path) | per wave { tile records | [F][65] u32 own counts }
+// forward, fused with its own population count.  One workgroup = one query tile.
+//   pass 1  every wave pre-filters its share of the candidate tiles, resolves the hits
+//           exactly, adds them to the shared [tap][lane] populations and keeps the hit masks
+//           of exact neighbours in LDS (mask slot = position in the wave's tile sequence);
+//   pass 2  after a barrier the populations are final: the waves walk their saved masks again
+//           and accumulate  out[i,c] += W[f,k,c] * (x[j,k] / count[i,f])      (.cpp:480-494)
+//           tiles beyond the mask capacity are simply searched again.
+// CIN/COUT > 0: output row in registers (one partial per wave, summed through LDS), filter in
+// LDS.  CIN == 0: generic shapes, single-wave workgroups, output row accumulated in
+// pre-zeroed global memory, filter read through L1/L2.
+// LDS: tapmap | filter | [F][65] u32 | masks [WAVES][cap][64] u64 | per wave SoA | reduce
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void forward_kernel(
-    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes,
-    const int32_t *__restrict__ count, const T *__restrict__ input, const T *__restrict__ filter,
-    Stencil<T> st, int N, int ntiles, int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output)
+    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const T *__restrict__ input,
+    const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int cin_rt, int cout_rt, int mask_cap,
+    BlockMap bm, T *__restrict__ output)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
     const int cout = kSmall ? COUT : cout_rt;
+    const int nwaves = blockDim.x >> 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
     T *w_lds = reinterpret_cast<T *>(smem + off);
     const size_t nw = (size_t)st.ntap * cin * cout;
     if (kSmall) off += align16(nw * sizeof(T));
-    const size_t per_wave = align16(sizeof(PointRec<T>) * kTile) + align16((size_t)st.ntap * kCntStride * 4);
-    char *wave_base = smem + off + per_wave * (threadIdx.x >> 6);
-    PointRec<T> *tile_lds = reinterpret_cast<PointRec<T> *>(wave_base);
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(wave_base + align16(sizeof(PointRec<T>) * kTile));
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
+    off += align16((size_t)st.ntap * kCntStride * 4);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint64_t *masks = reinterpret_cast<uint64_t *>(smem + off) + (size_t)wave * mask_cap * 64;
+    off += align16((size_t)nwaves * mask_cap * 64 * 8);
+    float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
+    off += align16((size_t)nwaves * 192 * 4);
+    T *red = reinterpret_cast<T *>(smem + off);   // [nwaves][COUT][64], small path only
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     if (kSmall)
         for (size_t e = threadIdx.x; e < nw; e += blockDim.x) w_lds[e] = filter[e];
+    for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
     __syncthreads();
 
-    int b, blk;
-    if (!block_to_cloud(bm, b, blk)) return;
-    const int lane = threadIdx.x & 63;
-    const int qt = blk * kWavesPerBlock + (threadIdx.x >> 6);
-    if (qt >= ntiles) return;
-
+    int b, qt;
+    const bool live = block_to_cloud(bm, b, qt);
+    if (!live) return;   // uniform for the whole workgroup
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
     const T *cloud_box = boxes + (size_t)b * ntiles * 6;
     Query<T> q;
     make_query(q, cloud_pts[(size_t)qt * kTile + lane], st);
+    const bool qvalid = q.orig >= 0;
 
-    // own tap populations -> LDS, [tap][lane]
-    for (int qq = 0; qq < kTile; ++qq) {
-        const int orig = __shfl(q.orig, qq);
-        if (orig < 0) continue;
-        const int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
-        for (int f = lane; f < st.ntap; f += 64) cnt[f * kCntStride + qq] = (uint32_t)row[f];
+    // ---- pass 1: populations + exact hit masks
+    {
+        int seen = 0, slot = 0;
+        for (int base = 0; base < ntiles; base += 64) {
+            uint64_t tiles = overlapping_tiles(cloud_box, ntiles, base, q);
+            while (tiles) {
+                const int ct = base + __builtin_ctzll(tiles);
+                tiles &= tiles - 1;
+                if ((seen++ & (nwaves - 1)) != wave) continue;
+                const PointRec<T> *tile = cloud_pts + (size_t)ct * kTile;
+                stage_tile(soa, tile[lane]);
+                __builtin_amdgcn_wave_barrier();
+                uint32_t m0, m1;
+                scan_tile(soa, q, st, m0, m1);
+                __builtin_amdgcn_wave_barrier();
+                if (!qvalid) m0 = m1 = 0;
+                uint32_t k0 = 0, k1 = 0;   // exact neighbours, same bit layout
+                for_each_bit(m0, m1, [&](int c) {
+                    const int f = exact_tap(tile[c], q, st, tapmap);
+                    if (f >= 0) {
+                        atomicAdd(&cnt[f * kCntStride + lane], 1u);
+                        if (c < 32) k0 |= 1u << (31 - c); else k1 |= 1u << (63 - c);
+                    }
+                });
+                if (slot < mask_cap) masks[(size_t)slot * 64 + lane] = ((uint64_t)k1 << 32) | k0;
+                ++slot;
+            }
+        }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
+    // ---- pass 2: accumulate
     const T *in_cloud = input + (size_t)b * N * cin;
-    T *out_row = output + ((size_t)b * N + (q.orig < 0 ? 0 : q.orig)) * cout;
-
+    T *out_row = output + ((size_t)b * N + (qvalid ? q.orig : 0)) * cout;
     T acc[kSmall ? COUT : 1];
     if (kSmall) {
 #pragma unroll
         for (int c = 0; c < COUT; ++c) acc[c] = (T)0;
     }
-
-    for_each_box_hit(cloud_pts, cloud_box, ntiles, q, tile_lds, [&](const PointRec<T> &v) {
-        const int tx = axis_tap(v.x, q.lo[0], st.voxel, st.full[0], tapmap);
-        const int ty = axis_tap(v.y, q.lo[1], st.voxel, st.full[1], tapmap + st.maxfull);
-        const int tz = axis_tap(v.z, q.lo[2], st.voxel, st.full[2], tapmap + 2 * st.maxfull);
-        if ((tx | ty | tz) < 0) return;                                  // hole (.cpp:285)
-        const int f = (tz * st.ext[1] + ty) * st.ext[0] + tx;            // .cpp:290
+    auto accumulate = [&](const PointRec<T> &v, int f) {
         const T denom = (T)cnt[f * kCntStride + lane];                   // (T)fsize, .cpp:483
         const T *xr = in_cloud + (size_t)v.idx * cin;
         if constexpr (kSmall) {
@@ -196,11 +341,53 @@ __global__ __launch_bounds__(256) void forward_kernel(
                     if (c0 + u < cout) out_row[c0 + u] += a[u];
             }
         }
-    });
+    };
+    {
+        int seen = 0, slot = 0;
+        for (int base = 0; base < ntiles; base += 64) {
+            uint64_t tiles = overlapping_tiles(cloud_box, ntiles, base, q);
+            while (tiles) {
+                const int ct = base + __builtin_ctzll(tiles);
+                tiles &= tiles - 1;
+                if ((seen++ & (nwaves - 1)) != wave) continue;
+                const PointRec<T> *tile = cloud_pts + (size_t)ct * kTile;
+                if (slot < mask_cap) {
+                    const uint64_t m = masks[(size_t)slot * 64 + lane];
+                    for_each_bit((uint32_t)m, (uint32_t)(m >> 32), [&](int c) {
+                        const PointRec<T> v = tile[c];
+                        const int f = exact_tap(v, q, st, tapmap);       // >= 0 by construction
+                        accumulate(v, f);
+                    });
+                } else {
+                    stage_tile(soa, tile[lane]);
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t m0, m1;
+                    scan_tile(soa, q, st, m0, m1);
+                    __builtin_amdgcn_wave_barrier();
+                    if (!qvalid) m0 = m1 = 0;
+                    for_each_bit(m0, m1, [&](int c) {
+                        const PointRec<T> v = tile[c];
+                        const int f = exact_tap(v, q, st, tapmap);
+                        if (f >= 0) accumulate(v, f);
+                    });
+                }
+                ++slot;
+            }
+        }
+    }
 
-    if (kSmall && q.orig >= 0) {
+    if constexpr (kSmall) {
+        // fixed-order sum of the per-wave partial rows
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) out_row[c] = acc[c];
+        for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
+        __syncthreads();
+        for (int e = threadIdx.x; e < COUT * 64; e += blockDim.x) {
+            const int c = e >> 6, l = e & 63;
+            T s = red[((size_t)0 * COUT + c) * 64 + l];
+            for (int w = 1; w < nwaves; ++w) s += red[((size_t)w * COUT + c) * 64 + l];
+            const int orig = __shfl(q.orig, l);   // every wave holds the same 64 queries
+            if (orig >= 0) output[((size_t)b * N + orig) * COUT + c] = s;
+        }
     }
 }
 
@@ -209,10 +396,11 @@ __global__ __launch_bounds__(256) void forward_kernel(
 //   f' = tap of j inside ii's box, clamp, NO inclusion re-test (.cpp:658-677),
 //   count = population of tap f' of ii, skipped when 0 (.cpp:678-679),
 //   g[c] = dY[ii,c] / count,  dX[j,k] += g[c] W[f',k,c],  dW[f',k,c] += g[c] X[j,k].
-// Small path: dX row and X row in registers, filter in LDS, dW accumulated in an LDS copy
-// shared by the workgroup (ds_add), written out as one partial per workgroup.
-// Generic path: dX row in pre-zeroed global memory (lane-owned), dW through global atomics
-// into partial slot 0 (the reduce kernel then just copies it).
+// Small path: one workgroup = one query tile, 4 waves split the candidate tiles; dX partial
+// rows in registers summed through LDS in a fixed order; filter in LDS; dW accumulated in an
+// LDS copy shared by the workgroup (ds_add), written out as one partial per workgroup.
+// Generic path: single-wave workgroups, dX row in pre-zeroed global memory (lane-owned), dW
+// through global atomics into partial slot 0.
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void backward_kernel(
@@ -224,6 +412,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
     const int cout = kSmall ? COUT : cout_rt;
+    const int nwaves = blockDim.x >> 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
@@ -232,8 +421,10 @@ __global__ __launch_bounds__(256) void backward_kernel(
     if (kSmall) off += align16(nw * sizeof(T));
     T *dw_lds = reinterpret_cast<T *>(smem + off);
     if (kSmall) off += align16(nw * sizeof(T));
-    const size_t per_wave = align16(sizeof(PointRec<T>) * kTile);
-    PointRec<T> *tile_lds = reinterpret_cast<PointRec<T> *>(smem + off + per_wave * (threadIdx.x >> 6));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
+    off += align16((size_t)nwaves * 192 * 4);
+    T *red = reinterpret_cast<T *>(smem + off);   // [nwaves][CIN][64], small path only
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     if (kSmall)
@@ -243,12 +434,10 @@ __global__ __launch_bounds__(256) void backward_kernel(
         }
     __syncthreads();
 
-    int b, blk;
-    const bool live = block_to_cloud(bm, b, blk);
-    const int lane = threadIdx.x & 63;
-    const int qt = blk * kWavesPerBlock + (threadIdx.x >> 6);
+    int b, qt;
+    const bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
 
-    if (live && qt < ntiles) {
+    if (live) {
         const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
         const T *cloud_box = boxes + (size_t)b * ntiles * 6;
         Query<T> q;
@@ -268,12 +457,10 @@ __global__ __launch_bounds__(256) void backward_kernel(
             }
         }
 
-        for_each_box_hit(cloud_pts, cloud_box, ntiles, q, tile_lds, [&](const PointRec<T> &v) {
-            // membership of ii in j's set includes j's own hole test (.cpp:285 via :652)
-            const int sx = axis_tap(v.x, q.lo[0], st.voxel, st.full[0], tapmap);
-            const int sy = axis_tap(v.y, q.lo[1], st.voxel, st.full[1], tapmap + st.maxfull);
-            const int sz = axis_tap(v.z, q.lo[2], st.voxel, st.full[2], tapmap + 2 * st.maxfull);
-            if ((sx | sy | sz) < 0) return;
+        // membership of ii in j's set (incl. j's own hole test, .cpp:285 via :652) is what
+        // for_each_neighbor delivers; the tap it reports (of ii inside j's box) is not used.
+        for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, nwaves,
+                          [&](const PointRec<T> &v, int) {
             // tap of j inside the box centred on ii (.cpp:662-677)
             const T lx = (T)((double)v.x - st.half[0]);
             const T ly = (T)((double)v.y - st.half[1]);
@@ -319,9 +506,17 @@ __global__ __launch_bounds__(256) void backward_kernel(
             }
         });
 
-        if (kSmall && q.orig >= 0) {
+        if constexpr (kSmall) {
 #pragma unroll
-            for (int k = 0; k < CIN; ++k) dx_row[k] = dx[k];
+            for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
+            __syncthreads();
+            for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
+                const int k = e >> 6, l = e & 63;
+                T s = red[((size_t)0 * CIN + k) * 64 + l];
+                for (int w = 1; w < nwaves; ++w) s += red[((size_t)w * CIN + k) * 64 + l];
+                const int orig = __shfl(q.orig, l);
+                if (orig >= 0) grad_input[((size_t)b * N + orig) * CIN + k] = s;
+            }
         }
     }
 
