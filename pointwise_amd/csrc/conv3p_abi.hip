@@ -235,8 +235,11 @@ int launch_backward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, 
 {
     const int nwaves = CI > 0 ? kWavesPerBlock : 1;
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    const size_t lds = lds_common(st) + (CI > 0 ? 2 * a16(nw * sizeof(T)) : 0) + a16((size_t)nwaves * 192 * 4) +
-                       (CI > 0 ? a16((size_t)nwaves * CI * 64 * sizeof(T)) : 0);
+    const size_t lds = lds_common(st) +
+                       (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) +
+                                     a16((size_t)64 * CI * sizeof(T)) + a16((size_t)nwaves * CI * 64 * sizeof(T))
+                               : 0) +
+                       a16((size_t)nwaves * 192 * 4);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_BACKWARD, s);
@@ -332,7 +335,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     TRY(rc);
     {
         Scope sc(K_REDUCE, s);
-        hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nw + 63) / 64)), dim3(256), 0, s,
+        hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nw + 63) / 64)), dim3(1024), 0, s,
                            w.partials, nslots, nw, grad_filter);
     }
     return hip_ok();

@@ -318,9 +318,10 @@ __global__ __launch_bounds__(256) void forward_kernel(
         const T denom = (T)cnt[f * kCntStride + lane];                   // (T)fsize, .cpp:483
         const T *xr = in_cloud + (size_t)v.idx * cin;
         if constexpr (kSmall) {
+            const T rcp = (T)1 / denom;                                  // one IEEE division per pair
             T xs[CIN];
 #pragma unroll
-            for (int k = 0; k < CIN; ++k) xs[k] = xr[k] / denom;         // x / count, .cpp:492
+            for (int k = 0; k < CIN; ++k) xs[k] = xr[k] * rcp;           // x / count, .cpp:492
             const T *wf = w_lds + (size_t)f * CIN * COUT;
 #pragma unroll
             for (int k = 0; k < CIN; ++k)
@@ -382,11 +383,10 @@ __global__ __launch_bounds__(256) void forward_kernel(
         for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
         __syncthreads();
         for (int e = threadIdx.x; e < COUT * 64; e += blockDim.x) {
-            const int c = e >> 6, l = e & 63;
-            T s = red[((size_t)0 * COUT + c) * 64 + l];
-            for (int w = 1; w < nwaves; ++w) s += red[((size_t)w * COUT + c) * 64 + l];
-            const int orig = __shfl(q.orig, l);   // every wave holds the same 64 queries
-            if (orig >= 0) output[((size_t)b * N + orig) * COUT + c] = s;
+            const int c = e >> 6;   // e & 63 == lane: every wave holds the same 64 queries
+            T s = red[((size_t)0 * COUT + c) * 64 + lane];
+            for (int w = 1; w < nwaves; ++w) s += red[((size_t)w * COUT + c) * 64 + lane];
+            if (qvalid) output[((size_t)b * N + q.orig) * COUT + c] = s;
         }
     }
 }
@@ -396,11 +396,20 @@ __global__ __launch_bounds__(256) void forward_kernel(
 //   f' = tap of j inside ii's box, clamp, NO inclusion re-test (.cpp:658-677),
 //   count = population of tap f' of ii, skipped when 0 (.cpp:678-679),
 //   g[c] = dY[ii,c] / count,  dX[j,k] += g[c] W[f',k,c],  dW[f',k,c] += g[c] X[j,k].
-// Small path: one workgroup = one query tile, 4 waves split the candidate tiles; dX partial
-// rows in registers summed through LDS in a fixed order; filter in LDS; dW accumulated in an
-// LDS copy shared by the workgroup (ds_add), written out as one partial per workgroup.
+//
+// Small path (one workgroup = one query tile, 4 waves split the candidate tiles):
+//   phase A  the hit loop only gathers  G[(f',c)][j] += dY[ii,c] * (1/count)  into LDS
+//            ([row][lane], stride 65: lane-private columns, conflict-free ds_add);
+//   phase B  lanes = rows (f',c):  dW[f',k,c] = sum_j G[row][j] * X[j,k]   (X tile broadcast
+//            from LDS), written straight to this workgroup's partial slot;
+//   phase C  lanes = centres j, waves split the rows:  dX[j,k] = sum_row G[row][j] * W[row][k]
+//            (W broadcast from LDS), per-wave partial rows summed through LDS in fixed order.
+//   Both contractions are dense and divergence-free; no float atomics leave the workgroup, and
+//   the only LDS atomics are phase A's (summation order inside a workgroup is the only
+//   non-fixed order in the op).
 // Generic path: single-wave workgroups, dX row in pre-zeroed global memory (lane-owned), dW
 // through global atomics into partial slot 0.
+// LDS small: tapmap | Wt [F*COUT][CIN] | G [F*COUT][65] | X tile [64][CIN] | per wave SoA | reduce
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void backward_kernel(
@@ -417,45 +426,47 @@ __global__ __launch_bounds__(256) void backward_kernel(
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
     const size_t nw = (size_t)st.ntap * cin * cout;
-    T *w_lds = reinterpret_cast<T *>(smem + off);
+    const int nrows = st.ntap * cout;
+    T *wt = reinterpret_cast<T *>(smem + off);        // Wt[row][k], row = f*COUT + c
     if (kSmall) off += align16(nw * sizeof(T));
-    T *dw_lds = reinterpret_cast<T *>(smem + off);
-    if (kSmall) off += align16(nw * sizeof(T));
+    T *G = reinterpret_cast<T *>(smem + off);         // G[row][65]
+    if (kSmall) off += align16((size_t)nrows * kCntStride * sizeof(T));
+    T *xt = reinterpret_cast<T *>(smem + off);        // X tile [64][CIN]
+    if (kSmall) off += align16((size_t)64 * cin * sizeof(T));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)nwaves * 192 * 4);
-    T *red = reinterpret_cast<T *>(smem + off);   // [nwaves][CIN][64], small path only
+    T *red = reinterpret_cast<T *>(smem + off);       // [nwaves][CIN][64], small path only
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    if (kSmall)
-        for (size_t e = threadIdx.x; e < nw; e += blockDim.x) {
-            w_lds[e] = filter[e];
-            dw_lds[e] = (T)0;
+    if (kSmall) {
+        for (int e = threadIdx.x; e < (int)nw; e += blockDim.x) {
+            const int row = e / CIN, k = e - row * CIN;
+            const int f = row / COUT, c = row - f * COUT;
+            wt[e] = filter[((size_t)f * CIN + k) * COUT + c];
         }
-    __syncthreads();
+        for (int e = threadIdx.x; e < nrows * kCntStride; e += blockDim.x) G[e] = (T)0;
+    }
 
     int b, qt;
     const bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
+    const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
+    const T *cloud_box = boxes + (size_t)(live ? b : 0) * ntiles * 6;
+    Query<T> q;
+    make_query(q, cloud_pts[(size_t)(live ? qt : 0) * kTile + lane], st);
+    if (!live) q.orig = -1;
+    const size_t jrow = (size_t)(live ? b : 0) * N + (q.orig < 0 ? 0 : q.orig);
+    if (kSmall && wave == 0) {
+#pragma unroll
+        for (int k = 0; k < (kSmall ? CIN : 1); ++k) xt[lane * cin + k] = q.orig >= 0 ? input[jrow * cin + k] : (T)0;
+    }
+    __syncthreads();
 
     if (live) {
-        const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
-        const T *cloud_box = boxes + (size_t)b * ntiles * 6;
-        Query<T> q;
-        make_query(q, cloud_pts[(size_t)qt * kTile + lane], st);
-        const size_t jrow = (size_t)b * N + (q.orig < 0 ? 0 : q.orig);
         const int32_t *cnt_cloud = count + (size_t)b * N * st.ntap;
         const T *dy_cloud = grad_out + (size_t)b * N * cout;
         const T *x_row = input + jrow * cin;
         T *dx_row = grad_input + jrow * cin;
-
-        T xj[kSmall ? CIN : 1], dx[kSmall ? CIN : 1];
-        if (kSmall) {
-#pragma unroll
-            for (int k = 0; k < CIN; ++k) {
-                xj[k] = q.orig >= 0 ? x_row[k] : (T)0;
-                dx[k] = (T)0;
-            }
-        }
 
         // membership of ii in j's set (incl. j's own hole test, .cpp:285 via :652) is what
         // for_each_neighbor delivers; the tap it reports (of ii inside j's box) is not used.
@@ -472,24 +483,16 @@ __global__ __launch_bounds__(256) void backward_kernel(
             const int f = (tz * st.ext[1] + ty) * st.ext[0] + tx;             // .cpp:677
             const int cn = cnt_cloud[(size_t)v.idx * st.ntap + f];
             if (cn == 0) return;                                              // .cpp:679
-            const T denom = (T)cn;
             const T *dyr = dy_cloud + (size_t)v.idx * cout;
             if constexpr (kSmall) {
-                T g[COUT];
+                const T rcp = (T)1 / (T)cn;
+                T *grow = G + ((size_t)f * COUT) * kCntStride + lane;
 #pragma unroll
-                for (int c = 0; c < COUT; ++c) g[c] = dyr[c] / denom;
-                const T *wf = w_lds + (size_t)f * CIN * COUT;
-                T *dwf = dw_lds + (size_t)f * CIN * COUT;
-#pragma unroll
-                for (int k = 0; k < CIN; ++k) {
-#pragma unroll
-                    for (int c = 0; c < COUT; ++c) {
-                        dx[k] = __builtin_fma(g[c], wf[k * COUT + c], dx[k]);           // .cpp:692
-                        __hip_atomic_fetch_add(&dwf[k * COUT + c], g[c] * xj[k], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);           // .cpp:696
-                    }
-                }
+                for (int c = 0; c < COUT; ++c)
+                    __hip_atomic_fetch_add(&grow[c * kCntStride], dyr[c] * rcp, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
+                const T denom = (T)cn;
                 const T *wf = filter + (size_t)f * cin * cout;
                 T *dwf = partials + (size_t)f * cin * cout;
                 for (int k = 0; k < cin; ++k) {
@@ -505,45 +508,80 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 }
             }
         });
-
-        if constexpr (kSmall) {
-#pragma unroll
-            for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
-            __syncthreads();
-            for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
-                const int k = e >> 6, l = e & 63;
-                T s = red[((size_t)0 * CIN + k) * 64 + l];
-                for (int w = 1; w < nwaves; ++w) s += red[((size_t)w * CIN + k) * 64 + l];
-                const int orig = __shfl(q.orig, l);
-                if (orig >= 0) grad_input[((size_t)b * N + orig) * CIN + k] = s;
-            }
-        }
     }
 
-    if (kSmall) {
+    if constexpr (kSmall) {
         __syncthreads();
+        // ---- phase B: dW rows.  thread = row (f,c); X tile read with wave-uniform addresses.
         T *slot = partials + (size_t)blockIdx.x * nw;
-        for (size_t e = threadIdx.x; e < nw; e += blockDim.x) slot[e] = dw_lds[e];
+        for (int row = threadIdx.x; row < nrows; row += blockDim.x) {
+            T acc[CIN];
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) acc[k] = (T)0;
+            const T *grow = G + (size_t)row * kCntStride;
+            for (int j = 0; j < 64; ++j) {
+                const T g = grow[j];
+#pragma unroll
+                for (int k = 0; k < CIN; ++k) acc[k] = __builtin_fma(g, xt[j * CIN + k], acc[k]);
+            }
+            const int f = row / COUT, c = row - f * COUT;
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) slot[((size_t)f * CIN + k) * COUT + c] = acc[k];
+        }
+        // ---- phase C: dX rows.  lane = centre j, waves split the rows.
+        T dx[CIN];
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
+        for (int row = wave; row < nrows; row += nwaves) {
+            const T g = G[(size_t)row * kCntStride + lane];
+            if (!__any(g != (T)0)) continue;
+            const T *wr = wt + (size_t)row * CIN;
+#pragma unroll
+            for (int k = 0; k < CIN; ++k) dx[k] = __builtin_fma(g, wr[k], dx[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
+        __syncthreads();
+        if (live)
+            for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
+                const int k = e >> 6;   // e & 63 == lane
+                T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+                for (int w = 1; w < nwaves; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
+                if (q.orig >= 0) grad_input[((size_t)b * N + q.orig) * CIN + k] = sum;
+            }
     }
 }
 
-// grad_filter[e] = sum over partial slots, fixed order (slot index ascending within a
-// thread's stripe, stripes combined in a fixed tree) -> run-to-run deterministic given
-// deterministic partials.
+// grad_filter[e] = sum over partial slots, fixed order (slot index ascending within a wave's
+// stripe, stripes combined in ascending wave order) -> run-to-run deterministic given
+// deterministic partials.  16 waves per workgroup stride over the slots; 64 weights per workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const T *__restrict__ partials,
-                                                              int nslots, size_t nw,
-                                                              T *__restrict__ grad_filter)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const T *__restrict__ partials,
+                                                               int nslots, size_t nw,
+                                                               T *__restrict__ grad_filter)
 {
-    __shared__ T part[kWavesPerBlock][64];
+    __shared__ T part[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t e = (size_t)blockIdx.x * 64 + lane;
-    T s = (T)0;
-    if (e < nw)
-        for (int p = wave; p < nslots; p += kWavesPerBlock) s += partials[(size_t)p * nw + e];
-    part[wave][lane] = s;
+    T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+    if (e < nw) {
+        int p = wave;
+        for (; p + 48 < nslots; p += 64) {
+            s0 += partials[(size_t)p * nw + e];
+            s1 += partials[(size_t)(p + 16) * nw + e];
+            s2 += partials[(size_t)(p + 32) * nw + e];
+            s3 += partials[(size_t)(p + 48) * nw + e];
+        }
+        for (; p < nslots; p += 16) s0 += partials[(size_t)p * nw + e];
+    }
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && e < nw) grad_filter[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (wave == 0 && e < nw) {
+        T s = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) s += part[w][lane];
+        grad_filter[e] = s;
+    }
 }
 
 // SELU (selu.py:22-26): scale * (x >= 0 ? x : alpha * (exp(x) - 1)).
