@@ -19,8 +19,8 @@ constexpr size_t kAlign = 256;
 inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 // ----------------------------------------------------------------------------- profiling
-enum Kind { K_PREP = 0, K_COUNT, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET, K_NKINDS };
-const char *const kKindName[K_NKINDS] = {"prep_kernel",  "count_kernel", "forward_kernel",
+enum Kind { K_PREP = 0, K_SEARCH, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET, K_NKINDS };
+const char *const kKindName[K_NKINDS] = {"prep_kernel",  "search_kernel", "forward_kernel",
                                          "backward_kernel", "reduce_partials_kernel",
                                          "selu_kernel",  "selu_grad_kernel", "memset"};
 struct Prof {
@@ -120,6 +120,11 @@ template <typename T> struct Workspace {
     PointRec<T> *pts;
     T *boxes;
     int32_t *count;
+    uint32_t *cursor;
+    uint2 *segs;
+    PairEntry *pairs;
+    uint32_t pair_cap;
+    int gtiles, ngroups;
     T *partials;
     int nslots;
     size_t bytes;
@@ -127,16 +132,28 @@ template <typename T> struct Workspace {
 
 inline bool small_shape(int elem, int cin, int cout);
 
+constexpr int kGroupTiles = 128;       // candidate tiles per search group (64 KiB of hit masks in LDS)
+constexpr size_t kPairsPerPoint = 64;  // pair-list capacity per point (average); overflow -> slow path
+
 template <typename T> Workspace<T> carve(const Dims &d, int pass, void *base)
 {
     Workspace<T> w{};
     size_t off = 0;
     char *p = static_cast<char *>(base);
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
+    w.gtiles = d.ntiles < kGroupTiles ? (d.ntiles > 0 ? d.ntiles : 1) : kGroupTiles;
+    w.ngroups = d.ntiles > 0 ? (d.ntiles + w.gtiles - 1) / w.gtiles : 1;
     w.pts = reinterpret_cast<PointRec<T> *>(take(sizeof(PointRec<T>) * (size_t)d.B * d.ntiles * kTile));
     w.boxes = reinterpret_cast<T *>(take(sizeof(T) * (size_t)d.B * d.ntiles * 6));
-    if (pass == CONV3P_PASS_BACKWARD)
+    w.cursor = reinterpret_cast<uint32_t *>(take(256));
+    if (pass != CONV3P_PASS_NEIGHBOR_COUNT) {
         w.count = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)d.B * d.N * d.ntap));
+        w.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)d.B * d.ntiles * w.ngroups));
+        size_t cap = (size_t)d.B * d.N * kPairsPerPoint;
+        if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+        w.pair_cap = (uint32_t)cap;
+        w.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * cap));
+    }
     if (pass == CONV3P_PASS_BACKWARD) {
         const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
         w.nslots = small_shape((int)sizeof(T), d.Cin, d.Cout) ? (int)grid_of(make_blockmap(d)) : 1;
@@ -182,25 +199,29 @@ int run_prep(const T *points, const Dims &d, const Workspace<T> &w, hipStream_t 
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(prep_sort_kernel<T>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(prep_sort_kernel<T>, dim3(d.B), dim3(threads), lds, s, points, d.N, d.ntiles, npad,
-                           w.pts, w.boxes);
+                           w.pts, w.boxes, w.cursor);
         return hip_ok();
     }
     dim3 grid((d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock, d.B);
-    hipLaunchKernelGGL(prep_kernel<T>, grid, dim3(256), 0, s, points, d.N, d.ntiles, w.pts, w.boxes);
+    hipLaunchKernelGGL(prep_kernel<T>, grid, dim3(256), 0, s, points, d.N, d.ntiles, w.pts, w.boxes, w.cursor);
     return hip_ok();
 }
 
 template <typename T>
-int run_count(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, int32_t *count, hipStream_t s)
+int run_search(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, int32_t *count, bool with_pairs,
+               hipStream_t s)
 {
-    const size_t lds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16((size_t)kWavesPerBlock * 192 * 4);
+    const size_t lds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) +
+                       a16((size_t)w.gtiles * 64 * 8) + a16((size_t)w.gtiles * 4) + 32 +
+                       a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 128 * 4);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
-    Scope sc(K_COUNT, s);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(count_kernel<T>),
+    Scope sc(K_SEARCH, s);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(search_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(count_kernel<T>, dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, st, d.N,
-                       d.ntiles, bm, count);
+    hipLaunchKernelGGL(search_kernel<T>, dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, st, d.N, d.ntiles,
+                       w.gtiles, w.ngroups, bm, count, with_pairs ? w.pairs : nullptr, w.pair_cap, w.cursor,
+                       w.segs);
     return hip_ok();
 }
 
@@ -208,24 +229,17 @@ template <typename T, int CI, int CO>
 int launch_forward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, const T *input,
                    const T *filter, T *output, hipStream_t s)
 {
-    const int nwaves = CI > 0 ? kWavesPerBlock : 1;
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    const size_t fixed = lds_common(st) + (CI > 0 ? a16(nw * sizeof(T)) : 0) + a16((size_t)st.ntap * kCntStride * 4) +
-                         a16((size_t)nwaves * 192 * 4) + (CI > 0 ? a16((size_t)nwaves * CO * 64 * sizeof(T)) : 0);
-    // hit-mask slots per wave: enough for every candidate tile if LDS allows, else the tail is re-searched
-    const size_t budget = 64 * 1024;
-    if (fixed > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
-    int cap = (d.ntiles + nwaves - 1) / nwaves;
-    const size_t room = budget > fixed ? (budget - fixed) / ((size_t)nwaves * 64 * 8) : 0;
-    if ((size_t)cap > room) cap = (int)room;
-    const size_t lds = fixed + a16((size_t)nwaves * cap * 64 * 8);
+    const size_t lds = lds_common(st) + (CI > 0 ? a16(nw * sizeof(T)) : 0) + a16((size_t)st.ntap * kCntStride * 4) +
+                       256 + a16((size_t)kWavesPerBlock * 192 * 4) +
+                       (CI > 0 ? a16((size_t)kWavesPerBlock * CO * kCntStride * sizeof(T)) : 0);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_FORWARD, s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(forward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(64 * nwaves), lds, s, w.pts, w.boxes,
-                       input, filter, st, d.N, d.ntiles, d.Cin, d.Cout, cap, bm, output);
+    hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, w.count,
+                       w.pairs, w.segs, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout, bm, output);
     return hip_ok();
 }
 
@@ -233,21 +247,20 @@ template <typename T, int CI, int CO>
 int launch_backward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, const T *grad_out,
                     const T *input, const T *filter, T *grad_input, hipStream_t s)
 {
-    const int nwaves = CI > 0 ? kWavesPerBlock : 1;
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
     const size_t lds = lds_common(st) +
                        (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) +
-                                     a16((size_t)64 * CI * sizeof(T)) + a16((size_t)nwaves * CI * 64 * sizeof(T))
+                                     a16((size_t)64 * CI * sizeof(T)) + a16((size_t)kWavesPerBlock * CI * 64 * sizeof(T))
                                : 0) +
-                       a16((size_t)nwaves * 192 * 4);
+                       256 + a16((size_t)kWavesPerBlock * 192 * 4);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_BACKWARD, s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(64 * nwaves), lds, s, w.pts, w.boxes,
-                       w.count, grad_out, input, filter, st, d.N, d.ntiles, d.Cin, d.Cout, bm, grad_input,
-                       w.partials);
+    hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, w.count,
+                       w.pairs, w.segs, grad_out, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout, bm,
+                       grad_input, w.partials);
     return hip_ok();
 }
 
@@ -283,6 +296,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     TRY(ws_check(ws, ws_bytes, w.bytes));
     const Stencil<T> st = make_stencil<T>(d, stride, voxel);
     TRY(run_prep<T>(points, d, w, s));
+    TRY(run_search<T>(d, st, w, w.count, true, s));
     if constexpr (sizeof(T) == 4) {
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \
@@ -316,7 +330,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     TRY(ws_check(ws, ws_bytes, w.bytes));
     const Stencil<T> st = make_stencil<T>(d, stride, voxel);
     TRY(run_prep<T>(points, d, w, s));
-    TRY(run_count<T>(d, st, w, w.count, s));
+    TRY(run_search<T>(d, st, w, w.count, true, s));
     int rc = CONV3P_ERR_UNSUPPORTED;
     int nslots = w.nslots;
     if constexpr (sizeof(T) == 4) {
@@ -354,7 +368,7 @@ int count_impl(const T *points, const int32_t *stride, T voxel, int B, int N, in
     TRY(ws_check(ws, ws_bytes, w.bytes));
     const Stencil<T> st = make_stencil<T>(d, stride, voxel);
     TRY(run_prep<T>(points, d, w, s));
-    return run_count<T>(d, st, w, count, s);
+    return run_search<T>(d, st, w, count, false, s);
 }
 
 template <typename T> int selu_impl(const T *x, T *y, size_t n, void *stream)

@@ -284,6 +284,49 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Pair lists.  The search kernel resolves every (centre j, neighbour ii) pair once and stores
+//   PairEntry{ cand = original index of ii,  code = fwd_tap | bwd_tap << 12 | q << 24 }
+// fwd_tap : tap of ii inside j's box                      (forward,  .cpp:280-290)
+// bwd_tap : tap of j inside ii's box, kNoTap for a hole   (backward, .cpp:662-677)
+// q       : lane (0..63) of the centre inside its query tile
+// All pairs of a query tile are contiguous (one segment per tile).  Entries whose exact test
+// failed (pre-filter false positives) carry fwd_tap = kNoTap and are skipped by the consumers.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kNoTap = 0xFFFu;
+constexpr uint32_t kSegOverflow = 0xFFFFFFFFu;
+struct PairEntry {
+    uint32_t cand;
+    uint32_t code;
+};
+__device__ __forceinline__ uint32_t pair_code(uint32_t fwd, uint32_t bwd, uint32_t q) { return fwd | (bwd << 12) | (q << 24); }
+__device__ __forceinline__ uint32_t code_fwd(uint32_t c) { return c & 0xFFFu; }
+__device__ __forceinline__ uint32_t code_bwd(uint32_t c) { return (c >> 12) & 0xFFFu; }
+__device__ __forceinline__ uint32_t code_q(uint32_t c) { return c >> 24; }
+
+// exclusive prefix sum of a small non-negative integer across the wave (returns total in `total`)
+__device__ __forceinline__ int wave_excl_scan(int v, int &total)
+{
+    const int lane = threadIdx.x & 63;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(inc, o);
+        if (lane >= o) inc += n;
+    }
+    total = __shfl(inc, 63);
+    return inc - v;
+}
+
+// Per-centre exact data kept in LDS for the dense (lane = pair) stages.
+template <typename T> struct CentreRec {
+    T p[3];
+    T lo[3];
+    T hi[3];
+    int32_t orig;
+};
+
 // (cloud, query tile) of a workgroup.  Workgroup b is placed on XCD b % 8 by the dispatcher
 // (observed, used for L2 locality only): clouds are dealt to XCDs round-robin and all tiles of
 // a cloud run on that cloud's XCD, so points / features / counts of a cloud stay in one XCD's

@@ -1,9 +1,9 @@
 // conv3p_kernels.hpp -- the gfx950 kernels of the conv3p operator pair.
 // See conv3p_device.hpp for the search structure; this file holds
 //   prep_kernel            stage points as 16-byte records + per-tile bounding boxes
-//   count_kernel           per-point, per-tap neighbour populations (Grid::neighbor_count)
-//   forward_kernel         Conv3p           (reference tf_conv3p_atrous.cpp:453-504)
-//   backward_kernel        Conv3pGrad       (reference tf_conv3p_atrous.cpp:608-716)
+//   search_kernel          neighbour search: per-tap populations (Grid::neighbor_count) + pair lists
+//   forward_kernel         Conv3p accumulate     (reference tf_conv3p_atrous.cpp:453-504)
+//   backward_kernel        Conv3pGrad accumulate (reference tf_conv3p_atrous.cpp:608-716)
 //   reduce_partials_kernel deterministic second stage of grad_filter
 //   selu kernels           the activation between the stack's layers (selu.py:22-26)
 #pragma once
@@ -20,8 +20,9 @@ namespace conv3p {
 template <typename T>
 __global__ __launch_bounds__(256) void prep_kernel(const T *__restrict__ points, int N, int ntiles,
                                                    PointRec<T> *__restrict__ pts,
-                                                   T *__restrict__ boxes)
+                                                   T *__restrict__ boxes, uint32_t *__restrict__ cursor)
 {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *cursor = 0;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -73,8 +74,9 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
 template <typename T>
 __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ points, int N, int ntiles,
                                                          int npad, PointRec<T> *__restrict__ pts,
-                                                         T *__restrict__ boxes)
+                                                         T *__restrict__ boxes, uint32_t *__restrict__ cursor)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     __shared__ float red[6][16];
@@ -177,74 +179,235 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
 // LDS carve helpers (all offsets multiples of 16 B; one extern array per kernel).
 __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// Workgroup geometry: WAVES waves share one query tile and split its candidate tiles.
-// WAVES = 4 for the register-resident ("small") paths; WAVES = 1 for the generic channel
-// path, whose output rows are accumulated in global memory and must have a single owner.
-
 // ---------------------------------------------------------------------------------
-// count: count[(b*N + i)*F + f] = neighbours of i in tap f   (.cpp:306-379)
-// LDS: tapmap | [F][65] u32 (shared by the workgroup, ds_add) | per wave SoA slot
+// search: the geometry of the op, done ONCE per (points, filter extents, stride, voxel).
+// One workgroup (4 waves) per query tile, candidate tiles in groups of at most `gtiles`:
+//   P1  pre-filter: waves split the candidate tiles; 64-bit hit masks + per-tile totals -> LDS
+//   P2  one reservation of `sum of totals` pair slots for the whole query tile (one global
+//       atomic per workgroup and group) -> all pairs of a query tile are contiguous
+//   P3  waves turn their masks into a dense stream of (centre, candidate) pairs, 64 at a time
+//       (lane = pair, all lanes busy): exact membership + forward tap with the reference's
+//       arithmetic (.cpp:277-290), population update (LDS ds_add), backward tap (.cpp:662-677),
+//       one PairEntry per pre-filter hit (false positives are stored as kNoTap entries)
+//   end populations -> count[(b*N + orig)*F + f]   (Grid::neighbor_count, .cpp:306-379)
+// pairs == nullptr: populations only (the public neighbour-count entry point).
+// If the pair buffer is full the segment is marked kSegOverflow; consumers then fall back to
+// searching that query tile themselves (slow, correct).
+// LDS: tapmap | cnt [F][65] | centres [64] | masks [gtiles][64] u64 | tot [gtiles] | misc |
+//      per wave: SoA slot [192] f32 + pair stream [128] u32
 // ---------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void count_kernel(const PointRec<T> *__restrict__ pts,
-                                                    const T *__restrict__ boxes, Stencil<T> st,
-                                                    int N, int ntiles, BlockMap bm,
-                                                    int32_t *__restrict__ count)
+__device__ __forceinline__ void load_centres(CentreRec<T> *centres, const Query<T> &q)
+{
+    if ((threadIdx.x >> 6) == 0) {
+        CentreRec<T> r;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            r.p[a] = q.p[a];
+            r.lo[a] = q.lo[a];
+            r.hi[a] = q.hi[a];
+        }
+        r.orig = q.orig;
+        centres[threadIdx.x & 63] = r;
+    }
+}
+
+// backward tap of centre p inside the box of candidate v; kNoTap for a hole (.cpp:662-677)
+template <typename T>
+__device__ __forceinline__ uint32_t backward_tap(const T *p, const PointRec<T> &v, const Stencil<T> &st,
+                                                 const int16_t *tapmap)
+{
+    const T lx = (T)((double)v.x - st.half[0]);
+    const T ly = (T)((double)v.y - st.half[1]);
+    const T lz = (T)((double)v.z - st.half[2]);
+    const int tx = axis_tap(p[0], lx, st.voxel, st.full[0], tapmap);
+    const int ty = axis_tap(p[1], ly, st.voxel, st.full[1], tapmap + st.maxfull);
+    const int tz = axis_tap(p[2], lz, st.voxel, st.full[2], tapmap + 2 * st.maxfull);
+    if ((tx | ty | tz) < 0) return kNoTap;                              // .cpp:672
+    return (uint32_t)((tz * st.ext[1] + ty) * st.ext[0] + tx);          // .cpp:677
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restrict__ pts,
+                                                     const T *__restrict__ boxes, Stencil<T> st, int N,
+                                                     int ntiles, int gtiles, int ngroups, BlockMap bm,
+                                                     int32_t *__restrict__ count,
+                                                     PairEntry *__restrict__ pairs, uint32_t cap,
+                                                     uint32_t *__restrict__ cursor, uint2 *__restrict__ segs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
     off += align16((size_t)st.ntap * kCntStride * 4);
+    CentreRec<T> *centres = reinterpret_cast<CentreRec<T> *>(smem + off);
+    off += align16(sizeof(CentreRec<T>) * 64);
+    uint64_t *masks = reinterpret_cast<uint64_t *>(smem + off);
+    off += align16((size_t)gtiles * 64 * 8);
+    uint32_t *tot = reinterpret_cast<uint32_t *>(smem + off);
+    off += align16((size_t)gtiles * 4);
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + off);   // [0..3] wave sums, [4] base, [5] ok
+    off += 32;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
+    off += align16((size_t)kWavesPerBlock * 192 * 4);
+    uint32_t *stream = reinterpret_cast<uint32_t *>(smem + off) + wave * 128;
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
-    __syncthreads();
 
     int b, qt;
-    if (!block_to_cloud(bm, b, qt)) return;
+    if (!block_to_cloud(bm, b, qt)) return;   // uniform for the workgroup
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
     const T *cloud_box = boxes + (size_t)b * ntiles * 6;
     Query<T> q;
     make_query(q, cloud_pts[(size_t)qt * kTile + lane], st);
-
-    for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
-                      [&](const PointRec<T> &, int f) { atomicAdd(&cnt[f * kCntStride + lane], 1u); });
+    const bool qvalid = q.orig >= 0;
+    load_centres(centres, q);
     __syncthreads();
-    // row-wise write-out: lanes = taps, waves take every 4th query (coalesced F*4-byte rows)
-    for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
-        const int orig = __shfl(q.orig, qq);
-        if (orig < 0) continue;
-        int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
-        for (int f = lane; f < st.ntap; f += 64) row[f] = (int32_t)cnt[f * kCntStride + qq];
+
+    for (int g = 0; g < ngroups; ++g) {
+        const int ct0 = g * gtiles;
+        const int ct1 = min(ntiles, ct0 + gtiles);
+        // ---- P1: pre-filter
+        for (int base = ct0; base < ct1; base += 64) {
+            uint64_t live = overlapping_tiles(cloud_box, ct1, base, q);
+            for (int i = wave; i < 64 && base + i < ct1; i += kWavesPerBlock) {
+                const int ct = base + i;
+                uint32_t n = 0;
+                if ((live >> i) & 1ull) {
+                    stage_tile(soa, cloud_pts[(size_t)ct * kTile + lane]);
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t m0, m1;
+                    scan_tile(soa, q, st, m0, m1);
+                    __builtin_amdgcn_wave_barrier();
+                    if (!qvalid) m0 = m1 = 0;
+                    masks[(size_t)(ct - ct0) * 64 + lane] = ((uint64_t)m1 << 32) | m0;
+                    n = __popc(m0) + __popc(m1);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+                }
+                if (lane == 0) tot[ct - ct0] = n;
+            }
+        }
+        __syncthreads();
+        // ---- P2: one reservation for the whole query tile
+        {
+            uint32_t wsum = 0;
+            for (int i = wave + lane * kWavesPerBlock; i < ct1 - ct0; i += 64 * kWavesPerBlock) wsum += tot[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+            if (lane == 0) misc[wave] = wsum;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t L = misc[0] + misc[1] + misc[2] + misc[3];
+            uint32_t base = 0, ok = 0;
+            if (pairs != nullptr) {
+                base = L ? atomicAdd(cursor, L) : 0u;
+                ok = (base <= cap && L <= cap - base) ? 1u : 0u;
+                segs[((size_t)b * ntiles + qt) * ngroups + g] = ok ? make_uint2(base, L) : make_uint2(0u, kSegOverflow);
+            }
+            misc[4] = base;
+            misc[5] = ok;
+        }
+        __syncthreads();
+        // ---- P3: dense exact stage
+        {
+            uint32_t pos = misc[4];
+            for (int w = 0; w < wave; ++w) pos += misc[w];
+            const bool emit = misc[5] != 0;
+            int have = 0;
+            auto drain = [&](int n) {
+                // lanes 0..n-1 each resolve one (centre, candidate) pair
+                if (lane < n) {
+                    const uint32_t e = stream[lane];
+                    const uint32_t ql = (e >> 6) & 63u, c = e & 63u, ct = e >> 12;
+                    const CentreRec<T> cr = centres[ql];
+                    const PointRec<T> v = cloud_pts[(size_t)ct * kTile + c];
+                    const bool out = (v.x < cr.lo[0]) | (v.x > cr.hi[0]) | (v.y < cr.lo[1]) | (v.y > cr.hi[1]) |
+                                     (v.z < cr.lo[2]) | (v.z > cr.hi[2]);                       // .cpp:277
+                    uint32_t fwd = kNoTap, bwd = kNoTap;
+                    if (!out) {
+                        const int tx = axis_tap(v.x, cr.lo[0], st.voxel, st.full[0], tapmap);
+                        const int ty = axis_tap(v.y, cr.lo[1], st.voxel, st.full[1], tapmap + st.maxfull);
+                        const int tz = axis_tap(v.z, cr.lo[2], st.voxel, st.full[2], tapmap + 2 * st.maxfull);
+                        if ((tx | ty | tz) >= 0) {                                              // .cpp:285
+                            fwd = (uint32_t)((tz * st.ext[1] + ty) * st.ext[0] + tx);           // .cpp:290
+                            atomicAdd(&cnt[fwd * kCntStride + ql], 1u);
+                            if (emit) bwd = backward_tap(cr.p, v, st, tapmap);
+                        }
+                    }
+                    if (emit) {
+                        PairEntry pe;
+                        pe.cand = (uint32_t)v.idx;
+                        pe.code = pair_code(fwd, bwd, ql);
+                        pairs[(size_t)pos + lane] = pe;
+                    }
+                }
+                pos += n;
+            };
+            for (int ctl = wave; ctl < ct1 - ct0; ctl += kWavesPerBlock) {
+                if (tot[ctl] == 0) continue;
+                uint64_t m = masks[(size_t)ctl * 64 + lane];
+                const uint32_t ctbits = (uint32_t)(ct0 + ctl) << 12;
+                while (true) {
+                    const uint64_t act = __ballot(m != 0);
+                    if (act == 0) break;
+                    if (m != 0) {
+                        const int P = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t c = (uint32_t)(P < 32 ? 31 - P : 95 - P);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
+                        stream[have + rank] = ctbits | ((uint32_t)lane << 6) | c;
+                    }
+                    have += __popcll(act);
+                    __builtin_amdgcn_wave_barrier();
+                    if (have >= 64) {
+                        drain(64);
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t carry = stream[64 + lane];
+                        __builtin_amdgcn_wave_barrier();
+                        stream[lane] = carry;
+                        have -= 64;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            if (have > 0) drain(have);
+        }
+        __syncthreads();
     }
+
+    // populations -> global, by original index (lanes = taps, waves take every 4th centre)
+    if (count != nullptr)
+        for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
+            const int orig = centres[qq].orig;
+            if (orig < 0) continue;
+            int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
+            for (int f = lane; f < st.ntap; f += 64) row[f] = (int32_t)cnt[f * kCntStride + qq];
+        }
 }
 
 // ---------------------------------------------------------------------------------
-// forward, fused with its own population count.  One workgroup = one query tile.
-//   pass 1  every wave pre-filters its share of the candidate tiles, resolves the hits
-//           exactly, adds them to the shared [tap][lane] populations and keeps the hit masks
-//           of exact neighbours in LDS (mask slot = position in the wave's tile sequence);
-//   pass 2  after a barrier the populations are final: the waves walk their saved masks again
-//           and accumulate  out[i,c] += W[f,k,c] * (x[j,k] / count[i,f])      (.cpp:480-494)
-//           tiles beyond the mask capacity are simply searched again.
-// CIN/COUT > 0: output row in registers (one partial per wave, summed through LDS), filter in
-// LDS.  CIN == 0: generic shapes, single-wave workgroups, output row accumulated in
-// pre-zeroed global memory, filter read through L1/L2.
-// LDS: tapmap | filter | [F][65] u32 | masks [WAVES][cap][64] u64 | per wave SoA | reduce
+// forward accumulate: out[i,c] = sum over pairs of W[f,k,c] * x[j,k] / count[i,f]  (.cpp:480-494)
+// One workgroup = one query tile; threads stride over the tile's pair segment (lane = pair).
+// Small path (CIN/COUT compile-time): filter in LDS, own populations in LDS, each wave adds
+// into its own [COUT][65] copy of the output tile (ds_add, no cross-wave atomics), the four
+// copies are summed in a fixed order.  Generic path: global atomics into the zeroed output.
+// A segment marked kSegOverflow makes the workgroup search its query tile itself.
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void forward_kernel(
-    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const T *__restrict__ input,
-    const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int cin_rt, int cout_rt, int mask_cap,
+    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
+    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const T *__restrict__ input,
+    const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, int cin_rt, int cout_rt,
     BlockMap bm, T *__restrict__ output)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
     const int cout = kSmall ? COUT : cout_rt;
-    const int nwaves = blockDim.x >> 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
@@ -253,175 +416,121 @@ __global__ __launch_bounds__(256) void forward_kernel(
     if (kSmall) off += align16(nw * sizeof(T));
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
     off += align16((size_t)st.ntap * kCntStride * 4);
+    int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
+    off += 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint64_t *masks = reinterpret_cast<uint64_t *>(smem + off) + (size_t)wave * mask_cap * 64;
-    off += align16((size_t)nwaves * mask_cap * 64 * 8);
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
-    off += align16((size_t)nwaves * 192 * 4);
-    T *red = reinterpret_cast<T *>(smem + off);   // [nwaves][COUT][64], small path only
+    off += align16((size_t)kWavesPerBlock * 192 * 4);
+    T *outw = reinterpret_cast<T *>(smem + off) + (size_t)wave * (kSmall ? COUT : 0) * kCntStride;
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    if (kSmall)
-        for (size_t e = threadIdx.x; e < nw; e += blockDim.x) w_lds[e] = filter[e];
-    for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
-    __syncthreads();
-
-    int b, qt;
-    const bool live = block_to_cloud(bm, b, qt);
-    if (!live) return;   // uniform for the whole workgroup
-    const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
-    const T *cloud_box = boxes + (size_t)b * ntiles * 6;
-    Query<T> q;
-    make_query(q, cloud_pts[(size_t)qt * kTile + lane], st);
-    const bool qvalid = q.orig >= 0;
-
-    // ---- pass 1: populations + exact hit masks
-    {
-        int seen = 0, slot = 0;
-        for (int base = 0; base < ntiles; base += 64) {
-            uint64_t tiles = overlapping_tiles(cloud_box, ntiles, base, q);
-            while (tiles) {
-                const int ct = base + __builtin_ctzll(tiles);
-                tiles &= tiles - 1;
-                if ((seen++ & (nwaves - 1)) != wave) continue;
-                const PointRec<T> *tile = cloud_pts + (size_t)ct * kTile;
-                stage_tile(soa, tile[lane]);
-                __builtin_amdgcn_wave_barrier();
-                uint32_t m0, m1;
-                scan_tile(soa, q, st, m0, m1);
-                __builtin_amdgcn_wave_barrier();
-                if (!qvalid) m0 = m1 = 0;
-                uint32_t k0 = 0, k1 = 0;   // exact neighbours, same bit layout
-                for_each_bit(m0, m1, [&](int c) {
-                    const int f = exact_tap(tile[c], q, st, tapmap);
-                    if (f >= 0) {
-                        atomicAdd(&cnt[f * kCntStride + lane], 1u);
-                        if (c < 32) k0 |= 1u << (31 - c); else k1 |= 1u << (63 - c);
-                    }
-                });
-                if (slot < mask_cap) masks[(size_t)slot * 64 + lane] = ((uint64_t)k1 << 32) | k0;
-                ++slot;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- pass 2: accumulate
-    const T *in_cloud = input + (size_t)b * N * cin;
-    T *out_row = output + ((size_t)b * N + (qvalid ? q.orig : 0)) * cout;
-    T acc[kSmall ? COUT : 1];
     if (kSmall) {
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = (T)0;
+        for (size_t e = threadIdx.x; e < nw; e += blockDim.x) w_lds[e] = filter[e];
+        for (int e = lane; e < COUT * kCntStride; e += 64) outw[e] = (T)0;
     }
-    auto accumulate = [&](const PointRec<T> &v, int f) {
-        const T denom = (T)cnt[f * kCntStride + lane];                   // (T)fsize, .cpp:483
-        const T *xr = in_cloud + (size_t)v.idx * cin;
+    int b, qt;
+    if (!block_to_cloud(bm, b, qt)) return;   // uniform
+    const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
+    const PointRec<T> me = cloud_pts[(size_t)qt * kTile + lane];
+    if (wave == 0) qorig[lane] = me.idx;
+    __syncthreads();
+    // own populations -> LDS [tap][centre]
+    for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
+        const int orig = qorig[qq];
+        if (orig < 0) continue;
+        const int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
+        for (int f = lane; f < st.ntap; f += 64) cnt[f * kCntStride + qq] = (uint32_t)row[f];
+    }
+    __syncthreads();
+
+    const T *in_cloud = input + (size_t)b * N * cin;
+    T *out_cloud = output + (size_t)b * N * cout;
+    auto accumulate = [&](uint32_t cand, uint32_t f, uint32_t ql) {
+        const T rcp = (T)1 / (T)cnt[f * kCntStride + ql];                // 1 / (T)fsize, .cpp:483
+        const T *xr = in_cloud + (size_t)cand * cin;
         if constexpr (kSmall) {
-            const T rcp = (T)1 / denom;                                  // one IEEE division per pair
             T xs[CIN];
 #pragma unroll
             for (int k = 0; k < CIN; ++k) xs[k] = xr[k] * rcp;           // x / count, .cpp:492
             const T *wf = w_lds + (size_t)f * CIN * COUT;
 #pragma unroll
-            for (int k = 0; k < CIN; ++k)
+            for (int c = 0; c < COUT; ++c) {
+                T a = (T)0;
 #pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[c] = __builtin_fma(wf[k * COUT + c], xs[k], acc[c]);
+                for (int k = 0; k < CIN; ++k) a = __builtin_fma(wf[k * COUT + c], xs[k], a);
+                __hip_atomic_fetch_add(&outw[c * kCntStride + ql], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         } else {
             const T *wf = filter + (size_t)f * cin * cout;
-            for (int c0 = 0; c0 < cout; c0 += 4) {
-                T a[4] = {(T)0, (T)0, (T)0, (T)0};
-                for (int k = 0; k < cin; ++k) {
-                    const T xs = xr[k] / denom;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (c0 + u < cout) a[u] = __builtin_fma(wf[(size_t)k * cout + c0 + u], xs, a[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (c0 + u < cout) out_row[c0 + u] += a[u];
+            T *orow = out_cloud + (size_t)qorig[ql] * cout;
+            for (int c = 0; c < cout; ++c) {
+                T a = (T)0;
+                for (int k = 0; k < cin; ++k) a = __builtin_fma(wf[(size_t)k * cout + c], xr[k] * rcp, a);
+                __hip_atomic_fetch_add(&orow[c], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
-    {
-        int seen = 0, slot = 0;
-        for (int base = 0; base < ntiles; base += 64) {
-            uint64_t tiles = overlapping_tiles(cloud_box, ntiles, base, q);
-            while (tiles) {
-                const int ct = base + __builtin_ctzll(tiles);
-                tiles &= tiles - 1;
-                if ((seen++ & (nwaves - 1)) != wave) continue;
-                const PointRec<T> *tile = cloud_pts + (size_t)ct * kTile;
-                if (slot < mask_cap) {
-                    const uint64_t m = masks[(size_t)slot * 64 + lane];
-                    for_each_bit((uint32_t)m, (uint32_t)(m >> 32), [&](int c) {
-                        const PointRec<T> v = tile[c];
-                        const int f = exact_tap(v, q, st, tapmap);       // >= 0 by construction
-                        accumulate(v, f);
-                    });
-                } else {
-                    stage_tile(soa, tile[lane]);
-                    __builtin_amdgcn_wave_barrier();
-                    uint32_t m0, m1;
-                    scan_tile(soa, q, st, m0, m1);
-                    __builtin_amdgcn_wave_barrier();
-                    if (!qvalid) m0 = m1 = 0;
-                    for_each_bit(m0, m1, [&](int c) {
-                        const PointRec<T> v = tile[c];
-                        const int f = exact_tap(v, q, st, tapmap);
-                        if (f >= 0) accumulate(v, f);
-                    });
-                }
-                ++slot;
+
+    const uint2 *myseg = segs + ((size_t)b * ntiles + qt) * ngroups;
+    bool overflow = false;
+    for (int g = 0; g < ngroups; ++g) overflow |= myseg[g].y == kSegOverflow;
+    if (!overflow) {
+        for (int g = 0; g < ngroups; ++g) {
+            const uint2 sg = myseg[g];
+            const PairEntry *pe = pairs + sg.x;
+            for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
+                const PairEntry en = pe[e];
+                const uint32_t f = code_fwd(en.code);
+                if (f != kNoTap) accumulate(en.cand, f, code_q(en.code));
             }
         }
+    } else {
+        // pair buffer was full for this tile: search it here (lane = centre)
+        const T *cloud_box = boxes + (size_t)b * ntiles * 6;
+        Query<T> q;
+        make_query(q, me, st);
+        for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
+                          [&](const PointRec<T> &v, int f) { accumulate((uint32_t)v.idx, (uint32_t)f, (uint32_t)lane); });
     }
 
     if constexpr (kSmall) {
-        // fixed-order sum of the per-wave partial rows
-#pragma unroll
-        for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
         __syncthreads();
+        const T *o0 = reinterpret_cast<T *>(smem + off);
         for (int e = threadIdx.x; e < COUT * 64; e += blockDim.x) {
-            const int c = e >> 6;   // e & 63 == lane: every wave holds the same 64 queries
-            T s = red[((size_t)0 * COUT + c) * 64 + lane];
-            for (int w = 1; w < nwaves; ++w) s += red[((size_t)w * COUT + c) * 64 + lane];
-            if (qvalid) output[((size_t)b * N + q.orig) * COUT + c] = s;
+            const int c = e >> 6;   // e & 63 == lane
+            T s = o0[c * kCntStride + lane];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) s += o0[((size_t)w * COUT + c) * kCntStride + lane];
+            if (me.idx >= 0) out_cloud[(size_t)me.idx * COUT + c] = s;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------
-// backward.  For centre j (the lane) and every ii in j's accepted set (.cpp:652):
-//   f' = tap of j inside ii's box, clamp, NO inclusion re-test (.cpp:658-677),
-//   count = population of tap f' of ii, skipped when 0 (.cpp:678-679),
+// backward accumulate.  For every stored pair (centre j = q, neighbour ii = cand):
+//   f' = bwd tap (tap of j inside ii's box, no inclusion re-test, .cpp:658-677; kNoTap = hole),
+//   count = population of tap f' of ii, pair skipped when 0 (.cpp:678-679),
 //   g[c] = dY[ii,c] / count,  dX[j,k] += g[c] W[f',k,c],  dW[f',k,c] += g[c] X[j,k].
-//
-// Small path (one workgroup = one query tile, 4 waves split the candidate tiles):
-//   phase A  the hit loop only gathers  G[(f',c)][j] += dY[ii,c] * (1/count)  into LDS
-//            ([row][lane], stride 65: lane-private columns, conflict-free ds_add);
-//   phase B  lanes = rows (f',c):  dW[f',k,c] = sum_j G[row][j] * X[j,k]   (X tile broadcast
-//            from LDS), written straight to this workgroup's partial slot;
-//   phase C  lanes = centres j, waves split the rows:  dX[j,k] = sum_row G[row][j] * W[row][k]
-//            (W broadcast from LDS), per-wave partial rows summed through LDS in fixed order.
-//   Both contractions are dense and divergence-free; no float atomics leave the workgroup, and
-//   the only LDS atomics are phase A's (summation order inside a workgroup is the only
-//   non-fixed order in the op).
-// Generic path: single-wave workgroups, dX row in pre-zeroed global memory (lane-owned), dW
-// through global atomics into partial slot 0.
-// LDS small: tapmap | Wt [F*COUT][CIN] | G [F*COUT][65] | X tile [64][CIN] | per wave SoA | reduce
+// Small path (one workgroup = one query tile):
+//   phase A  lane = pair:  G[(f',c)][j] += dY[ii,c] * (1/count)   (LDS, [row][65], ds_add)
+//   phase B  thread = row (f',c):  dW[f',k,c] = sum_j G[row][j] * X[j,k]  -> this workgroup's
+//            partial slot (X tile broadcast from LDS)
+//   phase C  lane = centre j, waves split the rows:  dX[j,k] = sum_row G[row][j] * W[row][k],
+//            per-wave partial rows summed through LDS in fixed order.
+//   Both contractions are dense and divergence-free; no float atomics leave the workgroup.
+// Generic path: lane = pair, global atomics into zeroed dX and partial slot 0.
+// LDS small: tapmap | Wt [F*COUT][CIN] | G [F*COUT][65] | X tile [64][CIN] | centres | SoA | reduce
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void backward_kernel(
-    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes,
-    const int32_t *__restrict__ count, const T *__restrict__ grad_out,
-    const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles,
+    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
+    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const T *__restrict__ grad_out,
+    const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
     int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ grad_input, T *__restrict__ partials)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
     const int cout = kSmall ? COUT : cout_rt;
-    const int nwaves = blockDim.x >> 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
@@ -433,10 +542,12 @@ __global__ __launch_bounds__(256) void backward_kernel(
     if (kSmall) off += align16((size_t)nrows * kCntStride * sizeof(T));
     T *xt = reinterpret_cast<T *>(smem + off);        // X tile [64][CIN]
     if (kSmall) off += align16((size_t)64 * cin * sizeof(T));
+    int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
+    off += 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
-    off += align16((size_t)nwaves * 192 * 4);
-    T *red = reinterpret_cast<T *>(smem + off);       // [nwaves][CIN][64], small path only
+    off += align16((size_t)kWavesPerBlock * 192 * 4);
+    T *red = reinterpret_cast<T *>(smem + off);       // [4][CIN][64], small path only
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     if (kSmall) {
@@ -451,63 +562,77 @@ __global__ __launch_bounds__(256) void backward_kernel(
     int b, qt;
     const bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
     const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
-    const T *cloud_box = boxes + (size_t)(live ? b : 0) * ntiles * 6;
-    Query<T> q;
-    make_query(q, cloud_pts[(size_t)(live ? qt : 0) * kTile + lane], st);
-    if (!live) q.orig = -1;
-    const size_t jrow = (size_t)(live ? b : 0) * N + (q.orig < 0 ? 0 : q.orig);
-    if (kSmall && wave == 0) {
+    PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
+    if (!live) me.idx = -1;
+    if (wave == 0) {
+        qorig[lane] = me.idx;
+        if (kSmall) {
+            const T *xr = input + ((size_t)(live ? b : 0) * N + (me.idx < 0 ? 0 : me.idx)) * cin;
 #pragma unroll
-        for (int k = 0; k < (kSmall ? CIN : 1); ++k) xt[lane * cin + k] = q.orig >= 0 ? input[jrow * cin + k] : (T)0;
+            for (int k = 0; k < (kSmall ? CIN : 1); ++k) xt[lane * cin + k] = me.idx >= 0 ? xr[k] : (T)0;
+        }
     }
     __syncthreads();
 
     if (live) {
         const int32_t *cnt_cloud = count + (size_t)b * N * st.ntap;
         const T *dy_cloud = grad_out + (size_t)b * N * cout;
-        const T *x_row = input + jrow * cin;
-        T *dx_row = grad_input + jrow * cin;
-
-        // membership of ii in j's set (incl. j's own hole test, .cpp:285 via :652) is what
-        // for_each_neighbor delivers; the tap it reports (of ii inside j's box) is not used.
-        for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, nwaves,
-                          [&](const PointRec<T> &v, int) {
-            // tap of j inside the box centred on ii (.cpp:662-677)
-            const T lx = (T)((double)v.x - st.half[0]);
-            const T ly = (T)((double)v.y - st.half[1]);
-            const T lz = (T)((double)v.z - st.half[2]);
-            const int tx = axis_tap(q.p[0], lx, st.voxel, st.full[0], tapmap);
-            const int ty = axis_tap(q.p[1], ly, st.voxel, st.full[1], tapmap + st.maxfull);
-            const int tz = axis_tap(q.p[2], lz, st.voxel, st.full[2], tapmap + 2 * st.maxfull);
-            if ((tx | ty | tz) < 0) return;                                   // .cpp:672
-            const int f = (tz * st.ext[1] + ty) * st.ext[0] + tx;             // .cpp:677
-            const int cn = cnt_cloud[(size_t)v.idx * st.ntap + f];
+        const T *in_cloud = input + (size_t)b * N * cin;
+        T *dx_cloud = grad_input + (size_t)b * N * cin;
+        auto accumulate = [&](uint32_t cand, uint32_t fb, uint32_t ql) {
+            const int cn = cnt_cloud[(size_t)cand * st.ntap + fb];
             if (cn == 0) return;                                              // .cpp:679
-            const T *dyr = dy_cloud + (size_t)v.idx * cout;
+            const T rcp = (T)1 / (T)cn;
+            const T *dyr = dy_cloud + (size_t)cand * cout;
             if constexpr (kSmall) {
-                const T rcp = (T)1 / (T)cn;
-                T *grow = G + ((size_t)f * COUT) * kCntStride + lane;
+                T *grow = G + ((size_t)fb * COUT) * kCntStride + ql;
 #pragma unroll
                 for (int c = 0; c < COUT; ++c)
                     __hip_atomic_fetch_add(&grow[c * kCntStride], dyr[c] * rcp, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
-                const T denom = (T)cn;
-                const T *wf = filter + (size_t)f * cin * cout;
-                T *dwf = partials + (size_t)f * cin * cout;
+                const int jo = qorig[ql];
+                const T *wf = filter + (size_t)fb * cin * cout;
+                T *dwf = partials + (size_t)fb * cin * cout;
+                const T *xr = in_cloud + (size_t)jo * cin;
+                T *dxr = dx_cloud + (size_t)jo * cin;
                 for (int k = 0; k < cin; ++k) {
-                    const T xk = x_row[k];
+                    const T xk = xr[k];
                     T a = (T)0;
                     for (int c = 0; c < cout; ++c) {
-                        const T g = dyr[c] / denom;
-                        a = __builtin_fma(g, wf[(size_t)k * cout + c], a);
+                        const T g = dyr[c] * rcp;
+                        a = __builtin_fma(g, wf[(size_t)k * cout + c], a);                    // .cpp:692
                         __hip_atomic_fetch_add(&dwf[(size_t)k * cout + c], g * xk, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                                               __HIP_MEMORY_SCOPE_AGENT);                     // .cpp:696
                     }
-                    dx_row[k] += a;
+                    __hip_atomic_fetch_add(&dxr[k], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-        });
+        };
+
+        const uint2 *myseg = segs + ((size_t)b * ntiles + qt) * ngroups;
+        bool overflow = false;
+        for (int g = 0; g < ngroups; ++g) overflow |= myseg[g].y == kSegOverflow;
+        if (!overflow) {
+            for (int g = 0; g < ngroups; ++g) {
+                const uint2 sg = myseg[g];
+                const PairEntry *pe = pairs + sg.x;
+                for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
+                    const PairEntry en = pe[e];
+                    const uint32_t fb = code_bwd(en.code);
+                    if (code_fwd(en.code) != kNoTap && fb != kNoTap) accumulate(en.cand, fb, code_q(en.code));
+                }
+            }
+        } else {
+            const T *cloud_box = boxes + (size_t)b * ntiles * 6;
+            Query<T> q;
+            make_query(q, me, st);
+            for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
+                              [&](const PointRec<T> &v, int) {
+                const uint32_t fb = backward_tap(q.p, v, st, tapmap);
+                if (fb != kNoTap) accumulate((uint32_t)v.idx, fb, (uint32_t)lane);
+            });
+        }
     }
 
     if constexpr (kSmall) {
@@ -532,7 +657,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
         T dx[CIN];
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
-        for (int row = wave; row < nrows; row += nwaves) {
+        for (int row = wave; row < nrows; row += kWavesPerBlock) {
             const T g = G[(size_t)row * kCntStride + lane];
             if (!__any(g != (T)0)) continue;
             const T *wr = wt + (size_t)row * CIN;
@@ -546,8 +671,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
             for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
                 const int k = e >> 6;   // e & 63 == lane
                 T sum = red[((size_t)0 * CIN + k) * 64 + lane];
-                for (int w = 1; w < nwaves; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
-                if (q.orig >= 0) grad_input[((size_t)b * N + q.orig) * CIN + k] = sum;
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
+                if (me.idx >= 0) grad_input[((size_t)b * N + me.idx) * CIN + k] = sum;
             }
     }
 }
