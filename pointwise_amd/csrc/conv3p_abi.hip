@@ -122,6 +122,7 @@ template <typename T> struct Workspace {
     int32_t *count;
     uint32_t *cursor;
     uint2 *segs;
+    uint2 *qsegs;
     PairEntry *pairs;
     uint32_t pair_cap;
     int gtiles, ngroups;
@@ -133,7 +134,7 @@ template <typename T> struct Workspace {
 inline bool small_shape(int elem, int cin, int cout);
 
 constexpr int kGroupTiles = 128;       // candidate tiles per search group (64 KiB of hit masks in LDS)
-constexpr size_t kPairsPerPoint = 64;  // pair-list capacity per point (average); overflow -> slow path
+constexpr size_t kPairsPerPoint = 128;  // pair-list capacity per point (average); overflow -> slow path
 
 template <typename T> Workspace<T> carve(const Dims &d, int pass, void *base)
 {
@@ -149,6 +150,7 @@ template <typename T> Workspace<T> carve(const Dims &d, int pass, void *base)
     if (pass != CONV3P_PASS_NEIGHBOR_COUNT) {
         w.count = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)d.B * d.N * d.ntap));
         w.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)d.B * d.ntiles * w.ngroups));
+        w.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)d.B * d.ntiles * w.ngroups * 64));
         size_t cap = (size_t)d.B * d.N * kPairsPerPoint;
         if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
         w.pair_cap = (uint32_t)cap;
@@ -212,8 +214,8 @@ int run_search(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, int32
                hipStream_t s)
 {
     const size_t lds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) +
-                       a16((size_t)w.gtiles * 64 * 8) + a16((size_t)w.gtiles * 4) + 32 +
-                       a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 128 * 4);
+                       a16((size_t)w.gtiles * 64 * 8) + a16((size_t)w.gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
+                       a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_SEARCH, s);
@@ -221,7 +223,7 @@ int run_search(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, int32
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(search_kernel<T>, dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, st, d.N, d.ntiles,
                        w.gtiles, w.ngroups, bm, count, with_pairs ? w.pairs : nullptr, w.pair_cap, w.cursor,
-                       w.segs);
+                       w.segs, w.qsegs);
     return hip_ok();
 }
 
@@ -232,14 +234,14 @@ int launch_forward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, c
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
     const size_t lds = lds_common(st) + (CI > 0 ? a16(nw * sizeof(T)) : 0) + a16((size_t)st.ntap * kCntStride * 4) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
-                       (CI > 0 ? a16((size_t)kWavesPerBlock * CO * kCntStride * sizeof(T)) : 0);
+                       (CI > 0 ? a16((size_t)kWavesPerBlock * CO * 64 * sizeof(T)) : 0);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_FORWARD, s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(forward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, w.count,
-                       w.pairs, w.segs, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout, bm, output);
+                       w.pairs, w.segs, w.qsegs, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout, bm, output);
     return hip_ok();
 }
 
@@ -259,8 +261,8 @@ int launch_backward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, 
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, w.count,
-                       w.pairs, w.segs, grad_out, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout, bm,
-                       grad_input, w.partials);
+                       w.pairs, w.segs, w.qsegs, grad_out, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout,
+                       bm, grad_input, w.partials);
     return hip_ok();
 }
 

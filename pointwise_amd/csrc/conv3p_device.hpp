@@ -89,6 +89,9 @@ template <typename T> __device__ __forceinline__ T wave_max(T v)
     return v;
 }
 
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T> struct Limits;
 template <> struct Limits<float> {
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }

@@ -184,7 +184,9 @@ __device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t
 // One workgroup (4 waves) per query tile, candidate tiles in groups of at most `gtiles`:
 //   P1  pre-filter: waves split the candidate tiles; 64-bit hit masks + per-tile totals -> LDS
 //   P2  one reservation of `sum of totals` pair slots for the whole query tile (one global
-//       atomic per workgroup and group) -> all pairs of a query tile are contiguous
+//       atomic per workgroup and group); inside it the pairs are laid out CENTRE-MAJOR (CSR):
+//       centre q owns slots [start_q, start_q + n_q), published in qsegs -> consumers run
+//       lane = centre with register accumulators and need no floating-point atomics
 //   P3  waves turn their masks into a dense stream of (centre, candidate) pairs, 64 at a time
 //       (lane = pair, all lanes busy): exact membership + forward tap with the reference's
 //       arithmetic (.cpp:277-290), population update (LDS ds_add), backward tap (.cpp:662-677),
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                                                      int ntiles, int gtiles, int ngroups, BlockMap bm,
                                                      int32_t *__restrict__ count,
                                                      PairEntry *__restrict__ pairs, uint32_t cap,
-                                                     uint32_t *__restrict__ cursor, uint2 *__restrict__ segs)
+                                                     uint32_t *__restrict__ cursor, uint2 *__restrict__ segs,
+                                                     uint2 *__restrict__ qsegs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
@@ -246,12 +249,14 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
     off += align16((size_t)gtiles * 64 * 8);
     uint32_t *tot = reinterpret_cast<uint32_t *>(smem + off);
     off += align16((size_t)gtiles * 4);
-    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + off);   // [0..3] wave sums, [4] base, [5] ok
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + off);   // [4] base, [5] ok
     off += 32;
+    uint32_t *nqw = reinterpret_cast<uint32_t *>(smem + off);    // [wave][centre] pre-filter hits, then slot offsets
+    off += kWavesPerBlock * 64 * 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
-    uint32_t *stream = reinterpret_cast<uint32_t *>(smem + off) + wave * 128;
+    uint32_t *stream = reinterpret_cast<uint32_t *>(smem + off) + wave * 256;   // [0..127] pair, [128..255] slot
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
@@ -270,11 +275,12 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
         const int ct0 = g * gtiles;
         const int ct1 = min(ntiles, ct0 + gtiles);
         // ---- P1: pre-filter
+        uint32_t mine = 0;   // this wave's pre-filter hits of centre `lane`
         for (int base = ct0; base < ct1; base += 64) {
             uint64_t live = overlapping_tiles(cloud_box, ct1, base, q);
             for (int i = wave; i < 64 && base + i < ct1; i += kWavesPerBlock) {
                 const int ct = base + i;
-                uint32_t n = 0;
+                uint32_t any = 0;
                 if ((live >> i) & 1ull) {
                     stage_tile(soa, cloud_pts[(size_t)ct * kTile + lane]);
                     __builtin_amdgcn_wave_barrier();
@@ -283,40 +289,50 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                     __builtin_amdgcn_wave_barrier();
                     if (!qvalid) m0 = m1 = 0;
                     masks[(size_t)(ct - ct0) * 64 + lane] = ((uint64_t)m1 << 32) | m0;
-                    n = __popc(m0) + __popc(m1);
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+                    mine += __popc(m0) + __popc(m1);
+                    any = __any((m0 | m1) != 0) ? 1u : 0u;
                 }
-                if (lane == 0) tot[ct - ct0] = n;
+                if (lane == 0) tot[ct - ct0] = any;
             }
         }
+        nqw[wave * 64 + lane] = mine;
         __syncthreads();
-        // ---- P2: one reservation for the whole query tile
-        {
-            uint32_t wsum = 0;
-            for (int i = wave + lane * kWavesPerBlock; i < ct1 - ct0; i += 64 * kWavesPerBlock) wsum += tot[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
-            if (lane == 0) misc[wave] = wsum;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t L = misc[0] + misc[1] + misc[2] + misc[3];
+        // ---- P2: one reservation for the whole query tile, centre-major slots inside it
+        if (wave == 0) {
+            const uint32_t n0 = nqw[lane], n1 = nqw[64 + lane], n2 = nqw[128 + lane], n3 = nqw[192 + lane];
+            const uint32_t nq = n0 + n1 + n2 + n3;
+            int L;
+            const uint32_t offq = (uint32_t)wave_excl_scan((int)nq, L);
             uint32_t base = 0, ok = 0;
             if (pairs != nullptr) {
-                base = L ? atomicAdd(cursor, L) : 0u;
-                ok = (base <= cap && L <= cap - base) ? 1u : 0u;
-                segs[((size_t)b * ntiles + qt) * ngroups + g] = ok ? make_uint2(base, L) : make_uint2(0u, kSegOverflow);
+                if (lane == 0) {
+                    base = L ? atomicAdd(cursor, (uint32_t)L) : 0u;
+                    ok = (base <= cap && (uint32_t)L <= cap - base) ? 1u : 0u;
+                    segs[((size_t)b * ntiles + qt) * ngroups + g] =
+                        ok ? make_uint2(base, (uint32_t)L) : make_uint2(0u, kSegOverflow);
+                    misc[4] = base;
+                    misc[5] = ok;
+                }
+                base = __shfl(base, 0);
+                ok = __shfl(ok, 0);
+                qsegs[(((size_t)b * ntiles + qt) * ngroups + g) * 64 + lane] =
+                    ok ? make_uint2(base + offq, nq) : make_uint2(0u, kSegOverflow);
+            } else if (lane == 0) {
+                misc[4] = 0;
+                misc[5] = 0;
             }
-            misc[4] = base;
-            misc[5] = ok;
+            // slot offsets (relative to base) of each wave's share of centre `lane`
+            nqw[lane] = offq;
+            nqw[64 + lane] = offq + n0;
+            nqw[128 + lane] = offq + n0 + n1;
+            nqw[192 + lane] = offq + n0 + n1 + n2;
         }
         __syncthreads();
         // ---- P3: dense exact stage
         {
-            uint32_t pos = misc[4];
-            for (int w = 0; w < wave; ++w) pos += misc[w];
+            const uint32_t gbase = misc[4];
             const bool emit = misc[5] != 0;
+            uint32_t myslot = nqw[wave * 64 + lane];   // next slot of centre `lane` for this wave
             int have = 0;
             auto drain = [&](int n) {
                 // lanes 0..n-1 each resolve one (centre, candidate) pair
@@ -342,10 +358,9 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                         PairEntry pe;
                         pe.cand = (uint32_t)v.idx;
                         pe.code = pair_code(fwd, bwd, ql);
-                        pairs[(size_t)pos + lane] = pe;
+                        pairs[(size_t)gbase + stream[128 + lane]] = pe;
                     }
                 }
-                pos += n;
             };
             for (int ctl = wave; ctl < ct1 - ct0; ctl += kWavesPerBlock) {
                 if (tot[ctl] == 0) continue;
@@ -361,15 +376,17 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
                         stream[have + rank] = ctbits | ((uint32_t)lane << 6) | c;
+                        stream[128 + have + rank] = myslot++;
                     }
                     have += __popcll(act);
                     __builtin_amdgcn_wave_barrier();
                     if (have >= 64) {
                         drain(64);
                         __builtin_amdgcn_wave_barrier();
-                        const uint32_t carry = stream[64 + lane];
+                        const uint32_t carry = stream[64 + lane], carry2 = stream[192 + lane];
                         __builtin_amdgcn_wave_barrier();
                         stream[lane] = carry;
+                        stream[128 + lane] = carry2;
                         have -= 64;
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -393,17 +410,18 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
 // ---------------------------------------------------------------------------------
 // forward accumulate: out[i,c] = sum over pairs of W[f,k,c] * x[j,k] / count[i,f]  (.cpp:480-494)
 // One workgroup = one query tile; threads stride over the tile's pair segment (lane = pair).
-// Small path (CIN/COUT compile-time): filter in LDS, own populations in LDS, each wave adds
-// into its own [COUT][65] copy of the output tile (ds_add, no cross-wave atomics), the four
-// copies are summed in a fixed order.  Generic path: global atomics into the zeroed output.
+// Small path (CIN/COUT compile-time): lane = centre, the four waves take every 4th pair of the
+// centre's list; filter and own populations in LDS; output row in registers, the four partial
+// rows summed through LDS in a fixed order (bitwise reproducible).  Generic path: thread = pair,
+// global atomics into the zeroed output.
 // A segment marked kSegOverflow makes the workgroup search its query tile itself.
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void forward_kernel(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
-    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const T *__restrict__ input,
-    const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, int cin_rt, int cout_rt,
-    BlockMap bm, T *__restrict__ output)
+    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
+    const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
+    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -421,13 +439,11 @@ __global__ __launch_bounds__(256) void forward_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
-    T *outw = reinterpret_cast<T *>(smem + off) + (size_t)wave * (kSmall ? COUT : 0) * kCntStride;
+    T *red = reinterpret_cast<T *>(smem + off);   // [4][COUT][64], small path only
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    if (kSmall) {
+    if (kSmall)
         for (size_t e = threadIdx.x; e < nw; e += blockDim.x) w_lds[e] = filter[e];
-        for (int e = lane; e < COUT * kCntStride; e += 64) outw[e] = (T)0;
-    }
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;   // uniform
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
@@ -445,6 +461,12 @@ __global__ __launch_bounds__(256) void forward_kernel(
 
     const T *in_cloud = input + (size_t)b * N * cin;
     T *out_cloud = output + (size_t)b * N * cout;
+    T acc[kSmall ? COUT : 1];
+    if (kSmall) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = (T)0;
+    }
+    // centre = lane `ql` (always this lane on the small path)
     auto accumulate = [&](uint32_t cand, uint32_t f, uint32_t ql) {
         const T rcp = (T)1 / (T)cnt[f * kCntStride + ql];                // 1 / (T)fsize, .cpp:483
         const T *xr = in_cloud + (size_t)cand * cin;
@@ -454,34 +476,44 @@ __global__ __launch_bounds__(256) void forward_kernel(
             for (int k = 0; k < CIN; ++k) xs[k] = xr[k] * rcp;           // x / count, .cpp:492
             const T *wf = w_lds + (size_t)f * CIN * COUT;
 #pragma unroll
-            for (int c = 0; c < COUT; ++c) {
-                T a = (T)0;
+            for (int k = 0; k < CIN; ++k)
 #pragma unroll
-                for (int k = 0; k < CIN; ++k) a = __builtin_fma(wf[k * COUT + c], xs[k], a);
-                __hip_atomic_fetch_add(&outw[c * kCntStride + ql], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+                for (int c = 0; c < COUT; ++c) acc[c] = fma_t(wf[k * COUT + c], xs[k], acc[c]);
         } else {
             const T *wf = filter + (size_t)f * cin * cout;
             T *orow = out_cloud + (size_t)qorig[ql] * cout;
             for (int c = 0; c < cout; ++c) {
                 T a = (T)0;
-                for (int k = 0; k < cin; ++k) a = __builtin_fma(wf[(size_t)k * cout + c], xr[k] * rcp, a);
+                for (int k = 0; k < cin; ++k) a = fma_t(wf[(size_t)k * cout + c], xr[k] * rcp, a);
                 __hip_atomic_fetch_add(&orow[c], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
 
-    const uint2 *myseg = segs + ((size_t)b * ntiles + qt) * ngroups;
+    const size_t tile_id = (size_t)b * ntiles + qt;
     bool overflow = false;
-    for (int g = 0; g < ngroups; ++g) overflow |= myseg[g].y == kSegOverflow;
+    for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
     if (!overflow) {
         for (int g = 0; g < ngroups; ++g) {
-            const uint2 sg = myseg[g];
-            const PairEntry *pe = pairs + sg.x;
-            for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
-                const PairEntry en = pe[e];
-                const uint32_t f = code_fwd(en.code);
-                if (f != kNoTap) accumulate(en.cand, f, code_q(en.code));
+            if constexpr (kSmall) {
+                // lane = centre; the four waves take every 4th pair of the centre's list
+                const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + lane];
+                const PairEntry *pe = pairs + sg.x;
+                for (uint32_t i = wave; __any(i < sg.y); i += kWavesPerBlock) {
+                    if (i < sg.y) {
+                        const PairEntry en = pe[i];
+                        const uint32_t f = code_fwd(en.code);
+                        if (f != kNoTap) accumulate(en.cand, f, (uint32_t)lane);
+                    }
+                }
+            } else {
+                const uint2 sg = segs[tile_id * ngroups + g];
+                const PairEntry *pe = pairs + sg.x;
+                for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
+                    const PairEntry en = pe[e];
+                    const uint32_t f = code_fwd(en.code);
+                    if (f != kNoTap) accumulate(en.cand, f, code_q(en.code));
+                }
             }
         }
     } else {
@@ -494,13 +526,15 @@ __global__ __launch_bounds__(256) void forward_kernel(
     }
 
     if constexpr (kSmall) {
+        // fixed-order sum of the per-wave partial rows
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
         __syncthreads();
-        const T *o0 = reinterpret_cast<T *>(smem + off);
         for (int e = threadIdx.x; e < COUT * 64; e += blockDim.x) {
             const int c = e >> 6;   // e & 63 == lane
-            T s = o0[c * kCntStride + lane];
+            T s = red[((size_t)0 * COUT + c) * 64 + lane];
 #pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) s += o0[((size_t)w * COUT + c) * kCntStride + lane];
+            for (int w = 1; w < kWavesPerBlock; ++w) s += red[((size_t)w * COUT + c) * 64 + lane];
             if (me.idx >= 0) out_cloud[(size_t)me.idx * COUT + c] = s;
         }
     }
@@ -512,21 +546,23 @@ __global__ __launch_bounds__(256) void forward_kernel(
 //   count = population of tap f' of ii, pair skipped when 0 (.cpp:678-679),
 //   g[c] = dY[ii,c] / count,  dX[j,k] += g[c] W[f',k,c],  dW[f',k,c] += g[c] X[j,k].
 // Small path (one workgroup = one query tile):
-//   phase A  lane = pair:  G[(f',c)][j] += dY[ii,c] * (1/count)   (LDS, [row][65], ds_add)
+//   phase A  lane = centre j walking its own pair list; wave w owns the taps f' == w (mod 4):
+//            G[(f',c)][j] += dY[ii,c] * (1/count)   (LDS [row][65], one writer per element, no atomics)
 //   phase B  thread = row (f',c):  dW[f',k,c] = sum_j G[row][j] * X[j,k]  -> this workgroup's
 //            partial slot (X tile broadcast from LDS)
 //   phase C  lane = centre j, waves split the rows:  dX[j,k] = sum_row G[row][j] * W[row][k],
 //            per-wave partial rows summed through LDS in fixed order.
-//   Both contractions are dense and divergence-free; no float atomics leave the workgroup.
+//   No floating-point atomics anywhere on this path: results are bitwise reproducible.
 // Generic path: lane = pair, global atomics into zeroed dX and partial slot 0.
 // LDS small: tapmap | Wt [F*COUT][CIN] | G [F*COUT][65] | X tile [64][CIN] | centres | SoA | reduce
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void backward_kernel(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
-    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const T *__restrict__ grad_out,
-    const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
-    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ grad_input, T *__restrict__ partials)
+    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
+    const T *__restrict__ grad_out, const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st,
+    int N, int ntiles, int ngroups, int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ grad_input,
+    T *__restrict__ partials)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -579,6 +615,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
         const T *dy_cloud = grad_out + (size_t)b * N * cout;
         const T *in_cloud = input + (size_t)b * N * cin;
         T *dx_cloud = grad_input + (size_t)b * N * cin;
+        // phase A.  Small path: lane = centre `ql` == lane; wave w owns the taps f' == w (mod 4), so
+        // every G element has exactly one writer and plain LDS read-modify-write is race-free.
         auto accumulate = [&](uint32_t cand, uint32_t fb, uint32_t ql) {
             const int cn = cnt_cloud[(size_t)cand * st.ntap + fb];
             if (cn == 0) return;                                              // .cpp:679
@@ -587,9 +625,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
             if constexpr (kSmall) {
                 T *grow = G + ((size_t)fb * COUT) * kCntStride + ql;
 #pragma unroll
-                for (int c = 0; c < COUT; ++c)
-                    __hip_atomic_fetch_add(&grow[c * kCntStride], dyr[c] * rcp, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += dyr[c] * rcp;
             } else {
                 const int jo = qorig[ql];
                 const T *wf = filter + (size_t)fb * cin * cout;
@@ -601,7 +637,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     T a = (T)0;
                     for (int c = 0; c < cout; ++c) {
                         const T g = dyr[c] * rcp;
-                        a = __builtin_fma(g, wf[(size_t)k * cout + c], a);                    // .cpp:692
+                        a = fma_t(g, wf[(size_t)k * cout + c], a);                            // .cpp:692
                         __hip_atomic_fetch_add(&dwf[(size_t)k * cout + c], g * xk, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);                     // .cpp:696
                     }
@@ -610,27 +646,44 @@ __global__ __launch_bounds__(256) void backward_kernel(
             }
         };
 
-        const uint2 *myseg = segs + ((size_t)b * ntiles + qt) * ngroups;
+        const size_t tile_id = (size_t)b * ntiles + qt;
         bool overflow = false;
-        for (int g = 0; g < ngroups; ++g) overflow |= myseg[g].y == kSegOverflow;
+        for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
         if (!overflow) {
             for (int g = 0; g < ngroups; ++g) {
-                const uint2 sg = myseg[g];
-                const PairEntry *pe = pairs + sg.x;
-                for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
-                    const PairEntry en = pe[e];
-                    const uint32_t fb = code_bwd(en.code);
-                    if (code_fwd(en.code) != kNoTap && fb != kNoTap) accumulate(en.cand, fb, code_q(en.code));
+                if constexpr (kSmall) {
+                    const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + lane];
+                    const PairEntry *pe = pairs + sg.x;
+                    for (uint32_t i = 0; __any(i < sg.y); ++i) {
+                        if (i < sg.y) {
+                            const PairEntry en = pe[i];
+                            const uint32_t fb = code_bwd(en.code);
+                            if (code_fwd(en.code) != kNoTap && fb != kNoTap && (int)(fb & (kWavesPerBlock - 1)) == wave)
+                                accumulate(en.cand, fb, (uint32_t)lane);
+                        }
+                    }
+                } else {
+                    const uint2 sg = segs[tile_id * ngroups + g];
+                    const PairEntry *pe = pairs + sg.x;
+                    for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
+                        const PairEntry en = pe[e];
+                        const uint32_t fb = code_bwd(en.code);
+                        if (code_fwd(en.code) != kNoTap && fb != kNoTap) accumulate(en.cand, fb, code_q(en.code));
+                    }
                 }
             }
         } else {
+            // pair buffer was full for this tile: search it here.  Small path: every wave must see every
+            // neighbour (it owns a tap subset), so each wave walks all candidate tiles; generic path: the
+            // waves split the candidate tiles (global atomics).
             const T *cloud_box = boxes + (size_t)b * ntiles * 6;
             Query<T> q;
             make_query(q, me, st);
-            for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
-                              [&](const PointRec<T> &v, int) {
+            for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, kSmall ? 0 : wave,
+                              kSmall ? 1 : kWavesPerBlock, [&](const PointRec<T> &v, int) {
                 const uint32_t fb = backward_tap(q.p, v, st, tapmap);
-                if (fb != kNoTap) accumulate((uint32_t)v.idx, fb, (uint32_t)lane);
+                if (fb != kNoTap && (!kSmall || (int)(fb & (kWavesPerBlock - 1)) == wave))
+                    accumulate((uint32_t)v.idx, fb, (uint32_t)lane);
             });
         }
     }
@@ -647,7 +700,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
             for (int j = 0; j < 64; ++j) {
                 const T g = grow[j];
 #pragma unroll
-                for (int k = 0; k < CIN; ++k) acc[k] = __builtin_fma(g, xt[j * CIN + k], acc[k]);
+                for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g, xt[j * CIN + k], acc[k]);
             }
             const int f = row / COUT, c = row - f * COUT;
 #pragma unroll
@@ -662,7 +715,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
             if (!__any(g != (T)0)) continue;
             const T *wr = wt + (size_t)row * CIN;
 #pragma unroll
-            for (int k = 0; k < CIN; ++k) dx[k] = __builtin_fma(g, wr[k], dx[k]);
+            for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
         }
 #pragma unroll
         for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
