@@ -103,16 +103,25 @@ def main():
     torch.cuda.set_device(dev)
     lib = _lib.load()
 
-    # synthetic ModelNet40-shaped batch; features == points (modelnet_provider.py:212-213)
-    P = synth.modelnet_like(B_PER_GPU, N_POINTS, seed=1234 + 2 + 1000 * rank)
+    # synthetic ModelNet40-shaped batches; features == points (modelnet_provider.py:212-213).
+    # Every step gets a DIFFERENT batch (NBATCH distinct batches resident in HBM, cycled), as in training:
+    # the neighbour cache therefore rebuilds its geometry every step (1 sort + 4 searches per step) and only
+    # saves the repeats INSIDE a step (8 op calls share one `points`).  Nothing is carried across steps.
+    NBATCH = 4
+    Ps = [synth.modelnet_like(B_PER_GPU, N_POINTS, seed=1234 + 2 + 1000 * rank + 17 * i) for i in range(NBATCH)]
+    P = Ps[0]
     ups_np = [synth.upstream_grad(B_PER_GPU, N_POINTS, stack.HIDDEN, 77 + li + 1000 * rank) for li in range(4)]
-    tP = torch.from_numpy(P).to(dev)
-    tX = tP.clone()
+    tPs = [torch.from_numpy(p).to(dev) for p in Ps]
+    tXs = [t.clone() for t in tPs]
+    tP, tX = tPs[0], tXs[0]
     ups = [torch.from_numpy(u).to(dev) for u in ups_np]
     st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234)
+    counter = [0]
 
     def step():
-        st.forward(tP, tX)
+        i = counter[0] % NBATCH
+        counter[0] += 1
+        st.forward(tPs[i], tXs[i])
         dx, fused = st.backward(ups)
         distributed.allreduce_weight_grads(fused)
         return dx, fused
@@ -173,7 +182,8 @@ def main():
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "cfg2 ModelNet40-shaped: B=32 clouds/GPU x N=2048, pointcnn2_acsd conv3p "
-                                      "stack 3->9 s1, 9->9 s2, 9->9 s3, 9->9 s4 (+SELU), forward+backward"
+                                      "stack 3->9 s1, 9->9 s2, 9->9 s3, 9->9 s4 (+SELU), forward+backward, "
+                                      "a different batch every step"
                                       + (", fused RCCL all-reduce of 7290 weight grads" if world > 1 else ""),
                           "global_batch": B_PER_GPU * world, "points_per_cloud": N_POINTS,
                           "parallelism": "dp%d" % world},

@@ -89,6 +89,61 @@ int conv3p_backward_f64(const double *grad_out, const double *points, const doub
                         double *grad_filter, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Neighbour cache (optional; not in the reference).
+ *
+ * Everything geometric the ops compute -- Morton-sorted point records, per-tap populations and
+ * the per-centre neighbour lists with their taps and normalisers -- depends only on `points` and
+ * on the stencil (filter extents, stride, voxel_size), not on features, weights or gradients.
+ * In the reference's models every layer of a step sees the same `points`, and Conv3pGrad repeats
+ * Conv3p's search (pointcnn2_acsd.py:48-66; tf_conv3p_atrous.cu recomputes neighbor_count in both
+ * ops).  The *_cached entry points keep that state in a caller-owned, persistent device buffer:
+ *
+ *   - `cache` must be zero-filled once before its first use and must not be written by the
+ *     caller afterwards; one cache serves one (B, N, dtype) at a time (a change of shape simply
+ *     invalidates it).  It also holds the per-call scratch, so no separate workspace is needed.
+ *   - Validity is decided ON THE DEVICE, per cloud: a 64-bit content hash of the raw coordinates
+ *     is recomputed every call (one light kernel) and compared with the hash the lists were built
+ *     from; the search / finalise kernels are launched every call and return immediately for
+ *     clouds whose lists are current.  There is no host synchronisation and no pointer-identity
+ *     assumption: a recycled or overwritten buffer can only cost a rebuild.
+ *   - `slots` stencils are kept at once (LRU): 4 for the classification stack, 5 for segmentation.
+ *   - Results are bitwise identical to the stateless entry points.
+ * The stateless conv3p_forward/backward_* run the very same kernels on `workspace` with the cache
+ * logic forced to "rebuild".
+ * ------------------------------------------------------------------------------------------- */
+typedef struct conv3p_cache_config {
+    int slots;           /* stencils cached simultaneously (1..64)                                   */
+    int max_taps;        /* largest fz*fy*fx that will be used with this cache (27 for 3x3x3)        */
+    int pairs_per_point; /* pair-list capacity per point, averaged over a cloud; 0 = default (128).
+                            A cloud that needs more is still handled correctly (slow path).        */
+    int max_Cin;         /* largest channel counts of a backward call (sizes the scratch for the   */
+    int max_Cout;        /*   per-workgroup grad_filter partials)                                    */
+} conv3p_cache_config;
+
+size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_config *cfg);
+/* Drop the host-side bookkeeping of a cache buffer (call before freeing it). */
+int conv3p_cache_forget(void *cache);
+
+int conv3p_forward_cached_f32(const float *points, const float *input, const float *filter,
+                              const int32_t *stride_xyz, float voxel_size, int B, int N, int Cin,
+                              int Cout, int fz, int fy, int fx, float *output, void *cache,
+                              size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+int conv3p_forward_cached_f64(const double *points, const double *input, const double *filter,
+                              const int32_t *stride_xyz, double voxel_size, int B, int N, int Cin,
+                              int Cout, int fz, int fy, int fx, double *output, void *cache,
+                              size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+int conv3p_backward_cached_f32(const float *grad_out, const float *points, const float *input,
+                               const float *filter, const int32_t *stride_xyz, float voxel_size,
+                               int B, int N, int Cin, int Cout, int fz, int fy, int fx,
+                               float *grad_input, float *grad_filter, void *cache,
+                               size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+int conv3p_backward_cached_f64(const double *grad_out, const double *points, const double *input,
+                               const double *filter, const int32_t *stride_xyz, double voxel_size,
+                               int B, int N, int Cin, int Cout, int fz, int fy, int fx,
+                               double *grad_input, double *grad_filter, void *cache,
+                               size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+
 /* Per-point, per-tap neighbour populations, int32 (B, N, fz*fy*fx) on the device.
  * Restates Grid::neighbor_count / kernelBuildNeighborCount
  * (tf_conv3p_atrous.cpp:306-379 / tf_conv3p_atrous.cu:288-343): the intermediate both

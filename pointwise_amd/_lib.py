@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libconv3p_hip.so")
+LIB_PATH = os.environ.get("CONV3P_HIP_LIB") or os.path.join(_HERE, "csrc", "libconv3p_hip.so")   # env override: developer A/B builds only
 
 OK = 0
 ERR_INVALID_ARGUMENT = 1
@@ -29,6 +29,8 @@ def _sig(real):
     return {
         "forward": (_i, [_vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
         "backward": (_i, [_vp, _vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+        "forward_cached": (_i, [_vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+        "backward_cached": (_i, [_vp, _vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
         "neighbor_count": (_i, [_vp, _vp, real, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
         "selu": (_i, [_vp, _vp, _sz, _vp]),
         "selu_grad": (_i, [_vp, _vp, _vp, _sz, _vp]),
@@ -36,8 +38,15 @@ def _sig(real):
     }
 
 
+class CacheConfig(ctypes.Structure):
+    """conv3p_cache_config of include/conv3p.h."""
+    _fields_ = [("slots", _i), ("max_taps", _i), ("pairs_per_point", _i), ("max_Cin", _i), ("max_Cout", _i)]
+
+
 SYMBOLS = {
     "conv3p_workspace_bytes": (_sz, [_i] * 9),
+    "conv3p_cache_bytes": (_sz, [_i, _i, _i, ctypes.POINTER(CacheConfig)]),
+    "conv3p_cache_forget": (_i, [_vp]),
     "conv3p_profile_enable": (_i, [_i]),
     "conv3p_profile_reset": (_i, []),
     "conv3p_profile_kinds": (_i, []),

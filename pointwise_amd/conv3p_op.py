@@ -45,6 +45,33 @@ def _workspace(device, nbytes):
     return buf, stream
 
 
+class NeighborCache:
+    """Caller-owned persistent device buffer for the *_cached entry points of include/conv3p.h.
+
+    One cache serves one (B, N, dtype) on one device.  It is zero-filled at creation; validity afterwards
+    is decided on the device by content hash, so reusing it with different clouds is always safe."""
+
+    def __init__(self, B, N, dtype, device, slots=5, max_taps=27, pairs_per_point=0, max_cin=36, max_cout=41):
+        lib = _lib.load()
+        self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout)
+        self.key = (int(B), int(N), dtype, torch.device(device))
+        esz = _SFX[dtype][2]
+        self.nbytes = lib.conv3p_cache_bytes(esz, B, N, ctypes.byref(self.cfg))
+        if self.nbytes == 0:
+            raise Conv3pInvalidArgument("bad neighbour-cache configuration")
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+
+    def fits(self, B, N, dtype, device, ntap, cin, cout):
+        return (self.key == (int(B), int(N), dtype, torch.device(device)) and ntap <= self.cfg.max_taps
+                and cin <= self.cfg.max_Cin and cout <= self.cfg.max_Cout)
+
+    def __del__(self):
+        try:
+            _lib.load().conv3p_cache_forget(self.buf.data_ptr())
+        except Exception:
+            pass
+
+
 def _require(cond, msg):
     if not cond:
         raise Conv3pInvalidArgument(msg)
@@ -104,10 +131,10 @@ def _call(fn, *args):
     raise Conv3pRuntimeError(msg)
 
 
-def conv3p(points, input, filter, stride, voxel_size):
+def conv3p(points, input, filter, stride, voxel_size, cache=None):
     """Conv3p forward.  points (B,N,3), input (B,N,Cin), filter (fz,fy,fx,Cin,Cout), stride [sx,sy,sz]
     (int32[3]), voxel_size T[1] -> output (B,N,Cout).  Mirrors conv3p_module.conv3p
-    (/root/reference/pointcnn2_acsd.py:12-13)."""
+    (/root/reference/pointcnn2_acsd.py:12-13).  cache (optional, not in the reference): a NeighborCache."""
     lib = _lib.load()
     _common_checks(points, input, filter)
     s3 = _stride_list(stride)
@@ -118,16 +145,23 @@ def conv3p(points, input, filter, stride, voxel_size):
     fz, fy, fx, Cin, Cout = filter.shape
     points, input, filter = points.contiguous(), input.contiguous(), filter.contiguous()
     out = torch.empty((B, N, Cout), dtype=points.dtype, device=dev)
-    need = lib.conv3p_workspace_bytes(_lib.PASS_FORWARD, esz, B, N, Cin, Cout, fz, fy, fx)
     with torch.cuda.device(dev):
-        ws, stream = _workspace(dev, need)
-        _call(getattr(lib, "conv3p_forward_" + sfx), points.data_ptr(), input.data_ptr(), filter.data_ptr(),
-              ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx, out.data_ptr(),
-              ws.data_ptr(), ws.numel(), stream.cuda_stream)
+        if cache is not None and cache.fits(B, N, points.dtype, dev, fz * fy * fx, Cin, Cout):
+            stream = torch.cuda.current_stream(dev)
+            _call(getattr(lib, "conv3p_forward_cached_" + sfx), points.data_ptr(), input.data_ptr(),
+                  filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx,
+                  out.data_ptr(), cache.buf.data_ptr(), cache.nbytes, ctypes.addressof(cache.cfg),
+                  stream.cuda_stream)
+        else:
+            need = lib.conv3p_workspace_bytes(_lib.PASS_FORWARD, esz, B, N, Cin, Cout, fz, fy, fx)
+            ws, stream = _workspace(dev, need)
+            _call(getattr(lib, "conv3p_forward_" + sfx), points.data_ptr(), input.data_ptr(), filter.data_ptr(),
+                  ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx, out.data_ptr(),
+                  ws.data_ptr(), ws.numel(), stream.cuda_stream)
     return out
 
 
-def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_filter_out=None):
+def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_filter_out=None, cache=None):
     """Conv3pGrad -> (grad_input, grad_filter).  Mirrors conv3p_module.conv3p_grad
     (/root/reference/pointcnn2_acsd.py:30; schema register_op.cpp:63-75).
     grad_filter_out (optional, not in the reference): a contiguous tensor shaped like filter to write
@@ -153,12 +187,19 @@ def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_
         dw = grad_filter_out
         if dw.shape != filter.shape or dw.dtype != filter.dtype or not dw.is_contiguous() or dw.device != dev:
             raise Conv3pInvalidArgument("grad_filter_out must be a contiguous tensor like filter")
-    need = lib.conv3p_workspace_bytes(_lib.PASS_BACKWARD, esz, B, N, Cin, Cout, fz, fy, fx)
     with torch.cuda.device(dev):
-        ws, stream = _workspace(dev, need)
-        _call(getattr(lib, "conv3p_backward_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
-              input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout,
-              fz, fy, fx, dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
+        if cache is not None and cache.fits(B, N, points.dtype, dev, fz * fy * fx, Cin, Cout):
+            stream = torch.cuda.current_stream(dev)
+            _call(getattr(lib, "conv3p_backward_cached_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
+                  input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
+                  Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
+                  ctypes.addressof(cache.cfg), stream.cuda_stream)
+        else:
+            need = lib.conv3p_workspace_bytes(_lib.PASS_BACKWARD, esz, B, N, Cin, Cout, fz, fy, fx)
+            ws, stream = _workspace(dev, need)
+            _call(getattr(lib, "conv3p_backward_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
+                  input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
+                  Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
     return dx, dw
 
 

@@ -2,12 +2,21 @@
 //
 // Replaces the host glue of the reference's GPU op (tf_conv3p_atrous.cu:541-642, :659-775):
 // no blocking D2H copies (stride / voxel arrive by value), no per-call temp allocation
-// (caller-provided workspace), no default-stream launches (everything on `stream`),
+// (caller-provided workspace / cache), no default-stream launches (everything on `stream`),
 // status codes instead of OP_REQUIRES / exit().
+//
+// Pipeline of one op call (all on the caller's stream, no host synchronisation):
+//   prep_sort_kernel   hash the clouds; re-sort + re-box only clouds whose content changed
+//   search_kernel      per-tap populations + centre-major pair lists   (skipped per cloud when
+//   finalise_kernel    normalisers of every pair                        the slot is current)
+//   forward_kernel / backward_kernel + reduce_partials_kernel          the accumulation
+// The stateless entry points run the same kernels on the caller's scratch with force = 1.
 #include "../../include/conv3p.h"
 #include "conv3p_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -19,10 +28,10 @@ constexpr size_t kAlign = 256;
 inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 // ----------------------------------------------------------------------------- profiling
-enum Kind { K_PREP = 0, K_SEARCH, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET, K_NKINDS };
-const char *const kKindName[K_NKINDS] = {"prep_kernel",  "search_kernel", "forward_kernel",
-                                         "backward_kernel", "reduce_partials_kernel",
-                                         "selu_kernel",  "selu_grad_kernel", "memset"};
+enum Kind { K_PREP = 0, K_SEARCH, K_FINALISE, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET, K_NKINDS };
+const char *const kKindName[K_NKINDS] = {"prep_kernel", "search_kernel", "finalise_kernel", "forward_kernel",
+                                         "backward_kernel", "reduce_partials_kernel", "selu_kernel",
+                                         "selu_grad_kernel", "memset"};
 struct Prof {
     std::mutex mu;
     bool on = false;
@@ -74,7 +83,7 @@ int check(Dims &d, const int32_t *stride, double voxel, bool need_channels)
     if (!stride || stride[0] <= 0 || stride[1] <= 0 || stride[2] <= 0) return CONV3P_ERR_INVALID_ARGUMENT;
     if (!(voxel > 0.0)) return CONV3P_ERR_INVALID_ARGUMENT;   // also rejects NaN
     const long long ntap = (long long)d.fz * d.fy * d.fx;
-    if (ntap > 4096) return CONV3P_ERR_UNSUPPORTED;
+    if (ntap >= (long long)kNoTap) return CONV3P_ERR_UNSUPPORTED;   // taps are 12-bit fields of the pair code
     d.ntap = (int)ntap;
     d.ntiles = (d.N + kTile - 1) / kTile;
     const int ext[3] = {d.fx, d.fy, d.fz};
@@ -105,6 +114,23 @@ template <typename T> Stencil<T> make_stencil(const Dims &d, const int32_t *stri
     return st;
 }
 
+// 64-bit tag of a stencil: what a cache slot was built for
+unsigned long long stencil_tag(const Dims &d, const int32_t *stride, double voxel, int elem)
+{
+    unsigned long long h = 0xcbf29ce484222325ull;
+    auto mix = [&](unsigned long long v) {
+        h ^= v;
+        h *= 0x100000001b3ull;
+        h ^= h >> 29;
+    };
+    unsigned long long vb;
+    std::memcpy(&vb, &voxel, 8);
+    mix((unsigned long long)d.fz); mix((unsigned long long)d.fy); mix((unsigned long long)d.fx);
+    mix((unsigned long long)stride[0]); mix((unsigned long long)stride[1]); mix((unsigned long long)stride[2]);
+    mix(vb); mix((unsigned long long)elem); mix((unsigned long long)d.B); mix((unsigned long long)d.N);
+    return h | 1ull;
+}
+
 BlockMap make_blockmap(const Dims &d)
 {
     BlockMap m;
@@ -115,54 +141,67 @@ BlockMap make_blockmap(const Dims &d)
 }
 inline unsigned grid_of(const BlockMap &m) { return 8u * (unsigned)m.rounds * (unsigned)m.blocks_per_cloud; }
 
-// ----------------------------------------------------------------------------- workspace
-template <typename T> struct Workspace {
+// ----------------------------------------------------------------------------- buffer layout
+// One layout serves both the per-call workspace (1 slot, rebuilt every call) and the persistent
+// neighbour cache (several slots).  Everything a slot holds depends only on (points, stencil).
+constexpr int kGroupTiles = 128;      // candidate tiles per search group (64 KiB of hit masks in LDS)
+constexpr int kDefaultPairsPerPoint = 128;
+
+template <typename T> struct Layout {
+    // per cloud, independent of the stencil
+    unsigned long long *hash;
+    uint32_t *version;
     PointRec<T> *pts;
     T *boxes;
-    int32_t *count;
-    uint32_t *cursor;
-    uint2 *segs;
-    uint2 *qsegs;
-    PairEntry *pairs;
-    uint32_t pair_cap;
+    // per slot
+    struct Slot {
+        uint32_t *built_version, *rebuilt, *cursor;
+        unsigned long long *built_tag;
+        int32_t *count;
+        uint2 *segs, *qsegs;
+        PairEntry *pairs;
+    };
+    std::vector<Slot> slot;
+    uint32_t pairs_per_cloud;
     int gtiles, ngroups;
+    // per-call scratch
     T *partials;
-    int nslots;
     size_t bytes;
 };
 
-inline bool small_shape(int elem, int cin, int cout);
-
-constexpr int kGroupTiles = 128;       // candidate tiles per search group (64 KiB of hit masks in LDS)
-constexpr size_t kPairsPerPoint = 128;  // pair-list capacity per point (average); overflow -> slow path
-
-template <typename T> Workspace<T> carve(const Dims &d, int pass, void *base)
+// ntap_max: taps the slots must be able to hold; scratch_bytes: bytes of per-call scratch
+template <typename T>
+Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_per_point, size_t scratch_bytes,
+                void *base)
 {
-    Workspace<T> w{};
+    Layout<T> L;
     size_t off = 0;
     char *p = static_cast<char *>(base);
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
-    w.gtiles = d.ntiles < kGroupTiles ? (d.ntiles > 0 ? d.ntiles : 1) : kGroupTiles;
-    w.ngroups = d.ntiles > 0 ? (d.ntiles + w.gtiles - 1) / w.gtiles : 1;
-    w.pts = reinterpret_cast<PointRec<T> *>(take(sizeof(PointRec<T>) * (size_t)d.B * d.ntiles * kTile));
-    w.boxes = reinterpret_cast<T *>(take(sizeof(T) * (size_t)d.B * d.ntiles * 6));
-    w.cursor = reinterpret_cast<uint32_t *>(take(256));
-    if (pass != CONV3P_PASS_NEIGHBOR_COUNT) {
-        w.count = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)d.B * d.N * d.ntap));
-        w.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)d.B * d.ntiles * w.ngroups));
-        w.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)d.B * d.ntiles * w.ngroups * 64));
-        size_t cap = (size_t)d.B * d.N * kPairsPerPoint;
-        if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-        w.pair_cap = (uint32_t)cap;
-        w.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * cap));
+    L.gtiles = ntiles < kGroupTiles ? (ntiles > 0 ? ntiles : 1) : kGroupTiles;
+    L.ngroups = ntiles > 0 ? (ntiles + L.gtiles - 1) / L.gtiles : 1;
+    L.hash = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)B));
+    L.version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
+    L.pts = reinterpret_cast<PointRec<T> *>(take(sizeof(PointRec<T>) * (size_t)B * ntiles * kTile));
+    L.boxes = reinterpret_cast<T *>(take(sizeof(T) * (size_t)B * ntiles * 6));
+    size_t ppc = (size_t)N * (size_t)pairs_per_point;
+    if ((size_t)B * ppc > 0xFFFFFFF0ull) ppc = B ? 0xFFFFFFF0ull / (size_t)B : 0;
+    L.pairs_per_cloud = (uint32_t)ppc;
+    L.slot.resize(nslots);
+    for (int s = 0; s < nslots; ++s) {
+        auto &S = L.slot[s];
+        S.built_version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
+        S.rebuilt = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
+        S.cursor = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
+        S.built_tag = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)B));
+        S.count = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)B * N * ntap_max));
+        S.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups));
+        S.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups * 64));
+        S.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * (size_t)B * ppc));
     }
-    if (pass == CONV3P_PASS_BACKWARD) {
-        const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
-        w.nslots = small_shape((int)sizeof(T), d.Cin, d.Cout) ? (int)grid_of(make_blockmap(d)) : 1;
-        w.partials = reinterpret_cast<T *>(take(sizeof(T) * nw * (size_t)w.nslots));
-    }
-    w.bytes = off;
-    return w;
+    L.partials = reinterpret_cast<T *>(take(scratch_bytes));
+    L.bytes = off;
+    return L;
 }
 
 // ----------------------------------------------------------------------------- dispatch table
@@ -180,6 +219,13 @@ inline bool small_shape(int elem, int cin, int cout)
     return false;
 }
 
+size_t backward_scratch_bytes(const Dims &d, int elem)
+{
+    const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
+    const size_t slots = small_shape(elem, d.Cin, d.Cout) ? (size_t)grid_of(make_blockmap(d)) : 1;
+    return nw * slots * (size_t)elem;
+}
+
 int hip_ok()
 {
     return hipGetLastError() == hipSuccess ? CONV3P_OK : CONV3P_ERR_LAUNCH;
@@ -189,66 +235,109 @@ template <typename T> size_t lds_common(const Stencil<T> &st) { return (3 * (siz
 inline size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
 constexpr size_t kMaxLds = 160 * 1024;
 
-template <typename T>
-int run_prep(const T *points, const Dims &d, const Workspace<T> &w, hipStream_t s)
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != CONV3P_OK) return rc_; } while (0)
+
+// Everything one call needs.
+template <typename T> struct Call {
+    Dims d;
+    Stencil<T> st;
+    Layout<T> L;
+    int slot;
+    CacheCtl cc;
+    hipStream_t s;
+};
+
+template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned long long tag, uint32_t epoch, int force)
 {
-    Scope sc(K_PREP, s);
+    CacheCtl cc;
+    cc.hash = L.hash;
+    cc.version = L.version;
+    cc.built_version = L.slot[slot].built_version;
+    cc.built_tag = L.slot[slot].built_tag;
+    cc.rebuilt = L.slot[slot].rebuilt;
+    cc.cursor = L.slot[slot].cursor;
+    cc.tag = tag;
+    cc.epoch = epoch;
+    cc.pairs_per_cloud = L.pairs_per_cloud;
+    cc.force = force;
+    return cc;
+}
+
+template <typename T> int run_prep(const T *points, const Call<T> &c)
+{
+    const Dims &d = c.d;
+    Scope sc(K_PREP, c.s);
     if (d.N <= 16384 && d.N > kTile) {
         int npad = 128;
         while (npad < d.N) npad <<= 1;
         const int threads = npad / 2 < 1024 ? (npad / 2 < 64 ? 64 : npad / 2) : 1024;
-        const size_t lds = (size_t)npad * 8;
+        const size_t lds = (size_t)npad * 8 + 256;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(prep_sort_kernel<T>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(prep_sort_kernel<T>, dim3(d.B), dim3(threads), lds, s, points, d.N, d.ntiles, npad,
-                           w.pts, w.boxes, w.cursor);
+        hipLaunchKernelGGL(prep_sort_kernel<T>, dim3(d.B), dim3(threads), lds, c.s, points, d.N, d.ntiles, npad,
+                           c.L.pts, c.L.boxes, c.cc);
         return hip_ok();
     }
     dim3 grid((d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock, d.B);
-    hipLaunchKernelGGL(prep_kernel<T>, grid, dim3(256), 0, s, points, d.N, d.ntiles, w.pts, w.boxes, w.cursor);
+    hipLaunchKernelGGL(prep_kernel<T>, grid, dim3(256), 0, c.s, points, d.N, d.ntiles, c.L.pts, c.L.boxes, c.cc);
     return hip_ok();
 }
 
-template <typename T>
-int run_search(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, int32_t *count, bool with_pairs,
-               hipStream_t s)
+// search (+ finalise when pair lists are wanted).  count: where the populations go.
+template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
+    const Dims &d = c.d;
+    const Stencil<T> &st = c.st;
+    const auto &S = c.L.slot[c.slot];
     const size_t lds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) +
-                       a16((size_t)w.gtiles * 64 * 8) + a16((size_t)w.gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
+                       a16((size_t)c.L.gtiles * 64 * 8) + a16((size_t)c.L.gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
                        a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
-    Scope sc(K_SEARCH, s);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(search_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(search_kernel<T>, dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, st, d.N, d.ntiles,
-                       w.gtiles, w.ngroups, bm, count, with_pairs ? w.pairs : nullptr, w.pair_cap, w.cursor,
-                       w.segs, w.qsegs);
+    {
+        Scope sc(K_SEARCH, c.s);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(search_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(search_kernel<T>, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes, st, d.N,
+                           d.ntiles, c.L.gtiles, c.L.ngroups, bm, count, with_pairs ? S.pairs : nullptr, c.cc,
+                           S.segs, S.qsegs);
+    }
+    TRY(hip_ok());
+    if (with_pairs) {
+        Scope sc2(K_FINALISE, c.s);
+        hipLaunchKernelGGL(finalise_kernel<T>, dim3(grid_of(bm)), dim3(256), 0, c.s, c.L.pts, count, d.N, d.ntiles,
+                           c.L.ngroups, st.ntap, bm, S.pairs, S.segs, c.cc);
+    }
     return hip_ok();
 }
 
 template <typename T, int CI, int CO>
-int launch_forward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, const T *input,
-                   const T *filter, T *output, hipStream_t s)
+int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output)
 {
+    const Dims &d = c.d;
+    const Stencil<T> &st = c.st;
+    const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
     const size_t lds = lds_common(st) + (CI > 0 ? a16(nw * sizeof(T)) : 0) + a16((size_t)st.ntap * kCntStride * 4) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
                        (CI > 0 ? a16((size_t)kWavesPerBlock * CO * 64 * sizeof(T)) : 0);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
-    Scope sc(K_FORWARD, s);
+    Scope sc(K_FORWARD, c.s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(forward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, w.count,
-                       w.pairs, w.segs, w.qsegs, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout, bm, output);
+    hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
+                       S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, d.Cin, d.Cout,
+                       bm, output);
     return hip_ok();
 }
 
 template <typename T, int CI, int CO>
-int launch_backward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, const T *grad_out,
-                    const T *input, const T *filter, T *grad_input, hipStream_t s)
+int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T *filter, T *grad_input)
 {
+    const Dims &d = c.d;
+    const Stencil<T> &st = c.st;
+    const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
     const size_t lds = lds_common(st) +
                        (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) +
@@ -257,12 +346,12 @@ int launch_backward(const Dims &d, const Stencil<T> &st, const Workspace<T> &w, 
                        256 + a16((size_t)kWavesPerBlock * 192 * 4);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
-    Scope sc(K_BACKWARD, s);
+    Scope sc(K_BACKWARD, c.s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, s, w.pts, w.boxes, w.count,
-                       w.pairs, w.segs, w.qsegs, grad_out, input, filter, st, d.N, d.ntiles, w.ngroups, d.Cin, d.Cout,
-                       bm, grad_input, w.partials);
+    hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
+                       S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
+                       d.Cin, d.Cout, bm, grad_input, c.L.partials);
     return hip_ok();
 }
 
@@ -273,19 +362,82 @@ int zero_async(void *p, size_t bytes, hipStream_t s)
     return hipMemsetAsync(p, 0, bytes, s) == hipSuccess ? CONV3P_OK : CONV3P_ERR_LAUNCH;
 }
 
-int ws_check(const void *ws, size_t have, size_t need)
+int buf_check(const void *p, size_t have, size_t need)
 {
     if (need == 0) return CONV3P_OK;
-    if (!ws || (reinterpret_cast<uintptr_t>(ws) % kAlign) != 0 || have < need) return CONV3P_ERR_WORKSPACE;
+    if (!p || (reinterpret_cast<uintptr_t>(p) % kAlign) != 0 || have < need) return CONV3P_ERR_WORKSPACE;
     return CONV3P_OK;
 }
 
-#define TRY(expr) do { int rc_ = (expr); if (rc_ != CONV3P_OK) return rc_; } while (0)
+// ----------------------------------------------------------------------------- cache (host side)
+// What the host remembers about a cache buffer: only which stencil tag lives in which slot
+// (LRU) and a call counter.  Validity itself is decided on the device (CacheCtl).
+struct CacheHost {
+    int B = -1, N = -1, elem = 0, ntap_max = 0, nslots = 0, ppp = 0;
+    std::vector<unsigned long long> tags;
+    std::vector<uint64_t> stamp;
+    uint64_t clock = 0;
+    uint32_t epoch = 0;
+};
+std::mutex g_cache_mu;
+std::map<void *, CacheHost> g_caches;
+
+// Describes where a call's state lives: a persistent cache or per-call scratch.
+struct Where {
+    void *buf;
+    size_t bytes;
+    bool persistent;
+    int nslots, ntap_max, ppp;
+    size_t scratch_cap;   // persistent: bytes of scratch the layout was sized with
+};
+
+template <typename T>
+int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t scratch, const Where &wh,
+               hipStream_t s)
+{
+    c.d = d;
+    c.st = make_stencil<T>(d, stride, voxel);
+    c.s = s;
+    const int ntap_max = wh.persistent ? wh.ntap_max : d.ntap;
+    if (d.ntap > ntap_max) return CONV3P_ERR_WORKSPACE;
+    if (wh.persistent && scratch > wh.scratch_cap) return CONV3P_ERR_WORKSPACE;
+    c.L = carve<T>(d.B, d.N, d.ntiles, ntap_max, wh.nslots, wh.ppp, wh.persistent ? wh.scratch_cap : scratch, wh.buf);
+    TRY(buf_check(wh.buf, wh.bytes, c.L.bytes));
+    const unsigned long long tag = stencil_tag(d, stride, (double)voxel, (int)sizeof(T));
+    if (!wh.persistent) {
+        c.slot = 0;
+        c.cc = make_ctl(c.L, 0, tag, 1u, /*force=*/1);
+        return CONV3P_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CacheHost &h = g_caches[wh.buf];
+    if (h.B != d.B || h.N != d.N || h.elem != (int)sizeof(T) || h.ntap_max != ntap_max || h.nslots != wh.nslots ||
+        h.ppp != wh.ppp) {
+        h = CacheHost();
+        h.B = d.B; h.N = d.N; h.elem = (int)sizeof(T); h.ntap_max = ntap_max; h.nslots = wh.nslots; h.ppp = wh.ppp;
+        h.tags.assign(wh.nslots, 0ull);
+        h.stamp.assign(wh.nslots, 0ull);
+    }
+    int slot = -1;
+    for (int i = 0; i < h.nslots; ++i)
+        if (h.tags[i] == tag) slot = i;
+    if (slot < 0) {   // least recently used slot; the device-side tag check forces its rebuild
+        slot = 0;
+        for (int i = 1; i < h.nslots; ++i)
+            if (h.stamp[i] < h.stamp[slot]) slot = i;
+        h.tags[slot] = tag;
+    }
+    h.stamp[slot] = ++h.clock;
+    h.epoch += 1;
+    if (h.epoch == 0) h.epoch = 1;
+    c.slot = slot;
+    c.cc = make_ctl(c.L, slot, tag, h.epoch, /*force=*/0);
+    return CONV3P_OK;
+}
 
 template <typename T>
 int forward_impl(const T *points, const T *input, const T *filter, const int32_t *stride, T voxel, int B,
-                 int N, int Cin, int Cout, int fz, int fy, int fx, T *output, void *ws, size_t ws_bytes,
-                 void *stream)
+                 int N, int Cin, int Cout, int fz, int fy, int fx, T *output, const Where &wh, void *stream)
 {
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     TRY(check(d, stride, (double)voxel, true));
@@ -294,28 +446,27 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     if (out_elems == 0) return CONV3P_OK;
     if (!points || !output || (Cin > 0 && (!input || !filter))) return CONV3P_ERR_INVALID_ARGUMENT;
     if (Cin == 0) return zero_async(output, out_elems * sizeof(T), s);   // empty contraction
-    Workspace<T> w = carve<T>(d, CONV3P_PASS_FORWARD, ws);
-    TRY(ws_check(ws, ws_bytes, w.bytes));
-    const Stencil<T> st = make_stencil<T>(d, stride, voxel);
-    TRY(run_prep<T>(points, d, w, s));
-    TRY(run_search<T>(d, st, w, w.count, true, s));
+    Call<T> c;
+    TRY(begin_call<T>(c, d, stride, voxel, 0, wh, s));
+    TRY(run_prep<T>(points, c));
+    TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     if constexpr (sizeof(T) == 4) {
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \
-        int rc = launch_forward<T, ci, co>(d, st, w, input, filter, output, s);                      \
+        int rc = launch_forward<T, ci, co>(c, input, filter, output);                                \
         if (rc != CONV3P_ERR_UNSUPPORTED) return rc;                                                 \
     }
         CONV3P_SMALL_SHAPES(X)
 #undef X
     }
     TRY(zero_async(output, out_elems * sizeof(T), s));                   // .cpp:451
-    return launch_forward<T, 0, 0>(d, st, w, input, filter, output, s);
+    return launch_forward<T, 0, 0>(c, input, filter, output);
 }
 
 template <typename T>
 int backward_impl(const T *grad_out, const T *points, const T *input, const T *filter,
                   const int32_t *stride, T voxel, int B, int N, int Cin, int Cout, int fz, int fy, int fx,
-                  T *grad_input, T *grad_filter, void *ws, size_t ws_bytes, void *stream)
+                  T *grad_input, T *grad_filter, const Where &wh, void *stream)
 {
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     TRY(check(d, stride, (double)voxel, true));
@@ -328,31 +479,29 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
         return zero_async(grad_filter, nw * sizeof(T), s);               // .cpp:590
     }
     if (!points || !input || !filter || !grad_out) return CONV3P_ERR_INVALID_ARGUMENT;
-    Workspace<T> w = carve<T>(d, CONV3P_PASS_BACKWARD, ws);
-    TRY(ws_check(ws, ws_bytes, w.bytes));
-    const Stencil<T> st = make_stencil<T>(d, stride, voxel);
-    TRY(run_prep<T>(points, d, w, s));
-    TRY(run_search<T>(d, st, w, w.count, true, s));
+    Call<T> c;
+    TRY(begin_call<T>(c, d, stride, voxel, backward_scratch_bytes(d, (int)sizeof(T)), wh, s));
+    TRY(run_prep<T>(points, c));
+    TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     int rc = CONV3P_ERR_UNSUPPORTED;
-    int nslots = w.nslots;
+    int nslots = (int)grid_of(make_blockmap(d));
     if constexpr (sizeof(T) == 4) {
 #define X(ci, co)                                                                                    \
-    if (Cin == ci && Cout == co)                                                                     \
-        rc = launch_backward<T, ci, co>(d, st, w, grad_out, input, filter, grad_input, s);
+    if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input);
         CONV3P_SMALL_SHAPES(X)
 #undef X
     }
     if (rc == CONV3P_ERR_UNSUPPORTED) {
         nslots = 1;
         TRY(zero_async(grad_input, dx_elems * sizeof(T), s));
-        TRY(zero_async(w.partials, nw * sizeof(T), s));
-        rc = launch_backward<T, 0, 0>(d, st, w, grad_out, input, filter, grad_input, s);
+        TRY(zero_async(c.L.partials, nw * sizeof(T), s));
+        rc = launch_backward<T, 0, 0>(c, grad_out, input, filter, grad_input);
     }
     TRY(rc);
     {
         Scope sc(K_REDUCE, s);
         hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nw + 63) / 64)), dim3(1024), 0, s,
-                           w.partials, nslots, nw, grad_filter);
+                           c.L.partials, nslots, nw, grad_filter);
     }
     return hip_ok();
 }
@@ -366,11 +515,11 @@ int count_impl(const T *points, const int32_t *stride, T voxel, int B, int N, in
     if ((size_t)B * N == 0) return CONV3P_OK;
     if (!points || !count) return CONV3P_ERR_INVALID_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Workspace<T> w = carve<T>(d, CONV3P_PASS_NEIGHBOR_COUNT, ws);
-    TRY(ws_check(ws, ws_bytes, w.bytes));
-    const Stencil<T> st = make_stencil<T>(d, stride, voxel);
-    TRY(run_prep<T>(points, d, w, s));
-    return run_search<T>(d, st, w, count, false, s);
+    Call<T> c;
+    const Where wh{ws, ws_bytes, false, 1, d.ntap, 0, 0};   // populations only: no pair storage
+    TRY(begin_call<T>(c, d, stride, voxel, 0, wh, s));
+    TRY(run_prep<T>(points, c));
+    return run_search<T>(c, count, false);
 }
 
 template <typename T> int selu_impl(const T *x, T *y, size_t n, void *stream)
@@ -394,6 +543,34 @@ template <typename T> int selu_grad_impl(const T *y, const T *dy, const T *dy_b,
     return hip_ok();
 }
 
+size_t layout_bytes(int elem, int B, int N, int ntap, int nslots, int ppp, size_t scratch)
+{
+    const int ntiles = (N + kTile - 1) / kTile;
+    return elem == 4 ? carve<float>(B, N, ntiles, ntap, nslots, ppp, scratch, nullptr).bytes
+                     : carve<double>(B, N, ntiles, ntap, nslots, ppp, scratch, nullptr).bytes;
+}
+
+size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, int max_Cout)
+{
+    Dims d{B, N, max_Cin, max_Cout, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};
+    return (size_t)max_taps * max_Cin * max_Cout * (size_t)grid_of(make_blockmap(d)) * (size_t)elem;
+}
+
+Where stateless(void *ws, size_t bytes) { return Where{ws, bytes, false, 1, 0, kDefaultPairsPerPoint, 0}; }
+
+Where persistent(int elem, int B, int N, void *cache, size_t bytes, int slots, int max_taps, int ppp, int max_Cin,
+                 int max_Cout)
+{
+    return Where{cache, bytes, true, slots, max_taps, ppp > 0 ? ppp : kDefaultPairsPerPoint,
+                 cache_scratch_bytes(elem, B, N, max_taps, max_Cin, max_Cout)};
+}
+
+bool cache_cfg_ok(const conv3p_cache_config *cfg)
+{
+    return cfg && cfg->slots > 0 && cfg->slots <= 64 && cfg->max_taps > 0 && cfg->max_taps < (int)kNoTap &&
+           cfg->max_Cin >= 0 && cfg->max_Cout >= 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -405,42 +582,79 @@ size_t conv3p_workspace_bytes(int pass, int elem_bytes, int B, int N, int Cin, i
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     const int32_t one[3] = {1, 1, 1};
     if (check(d, one, 1.0, pass != CONV3P_PASS_NEIGHBOR_COUNT) != CONV3P_OK) return 0;
-    const size_t b = elem_bytes == 4 ? carve<float>(d, pass, nullptr).bytes : carve<double>(d, pass, nullptr).bytes;
+    const int ppp = pass == CONV3P_PASS_NEIGHBOR_COUNT ? 0 : kDefaultPairsPerPoint;
+    const size_t scratch = pass == CONV3P_PASS_BACKWARD ? backward_scratch_bytes(d, elem_bytes) : 0;
+    const size_t b = layout_bytes(elem_bytes, B, N, d.ntap, 1, ppp, scratch);
     return b ? b : kAlign;
 }
 
-int conv3p_forward_f32(const float *points, const float *input, const float *filter,
-                       const int32_t *stride_xyz, float voxel_size, int B, int N, int Cin, int Cout,
-                       int fz, int fy, int fx, float *output, void *workspace, size_t workspace_bytes,
-                       void *stream)
+size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_config *cfg)
 {
-    return forward_impl<float>(points, input, filter, stride_xyz, voxel_size, B, N, Cin, Cout, fz, fy, fx,
-                               output, workspace, workspace_bytes, stream);
+    if ((elem_bytes != 4 && elem_bytes != 8) || B < 0 || N < 0 || !cache_cfg_ok(cfg)) return 0;
+    const int ppp = cfg->pairs_per_point > 0 ? cfg->pairs_per_point : kDefaultPairsPerPoint;
+    return layout_bytes(elem_bytes, B, N, cfg->max_taps, cfg->slots, ppp,
+                        cache_scratch_bytes(elem_bytes, B, N, cfg->max_taps, cfg->max_Cin, cfg->max_Cout));
 }
-int conv3p_forward_f64(const double *points, const double *input, const double *filter,
-                       const int32_t *stride_xyz, double voxel_size, int B, int N, int Cin, int Cout,
-                       int fz, int fy, int fx, double *output, void *workspace, size_t workspace_bytes,
-                       void *stream)
+
+int conv3p_cache_forget(void *cache)
 {
-    return forward_impl<double>(points, input, filter, stride_xyz, voxel_size, B, N, Cin, Cout, fz, fy, fx,
-                                output, workspace, workspace_bytes, stream);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_caches.erase(cache);
+    return CONV3P_OK;
 }
-int conv3p_backward_f32(const float *grad_out, const float *points, const float *input,
-                        const float *filter, const int32_t *stride_xyz, float voxel_size, int B, int N,
-                        int Cin, int Cout, int fz, int fy, int fx, float *grad_input, float *grad_filter,
-                        void *workspace, size_t workspace_bytes, void *stream)
+
+#define FWD_ARGS(T)                                                                                            \
+    const T *points, const T *input, const T *filter, const int32_t *stride_xyz, T voxel_size, int B, int N,   \
+        int Cin, int Cout, int fz, int fy, int fx, T *output
+#define FWD_PASS points, input, filter, stride_xyz, voxel_size, B, N, Cin, Cout, fz, fy, fx, output
+#define BWD_ARGS(T)                                                                                            \
+    const T *grad_out, const T *points, const T *input, const T *filter, const int32_t *stride_xyz,            \
+        T voxel_size, int B, int N, int Cin, int Cout, int fz, int fy, int fx, T *grad_input, T *grad_filter
+#define BWD_PASS                                                                                               \
+    grad_out, points, input, filter, stride_xyz, voxel_size, B, N, Cin, Cout, fz, fy, fx, grad_input, grad_filter
+
+int conv3p_forward_f32(FWD_ARGS(float), void *workspace, size_t workspace_bytes, void *stream)
 {
-    return backward_impl<float>(grad_out, points, input, filter, stride_xyz, voxel_size, B, N, Cin, Cout, fz,
-                                fy, fx, grad_input, grad_filter, workspace, workspace_bytes, stream);
+    return forward_impl<float>(FWD_PASS, stateless(workspace, workspace_bytes), stream);
 }
-int conv3p_backward_f64(const double *grad_out, const double *points, const double *input,
-                        const double *filter, const int32_t *stride_xyz, double voxel_size, int B, int N,
-                        int Cin, int Cout, int fz, int fy, int fx, double *grad_input,
-                        double *grad_filter, void *workspace, size_t workspace_bytes, void *stream)
+int conv3p_forward_f64(FWD_ARGS(double), void *workspace, size_t workspace_bytes, void *stream)
 {
-    return backward_impl<double>(grad_out, points, input, filter, stride_xyz, voxel_size, B, N, Cin, Cout, fz,
-                                 fy, fx, grad_input, grad_filter, workspace, workspace_bytes, stream);
+    return forward_impl<double>(FWD_PASS, stateless(workspace, workspace_bytes), stream);
 }
+int conv3p_backward_f32(BWD_ARGS(float), void *workspace, size_t workspace_bytes, void *stream)
+{
+    return backward_impl<float>(BWD_PASS, stateless(workspace, workspace_bytes), stream);
+}
+int conv3p_backward_f64(BWD_ARGS(double), void *workspace, size_t workspace_bytes, void *stream)
+{
+    return backward_impl<double>(BWD_PASS, stateless(workspace, workspace_bytes), stream);
+}
+
+#define CACHE_ARGS void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream
+#define CACHE_WHERE(elem)                                                                                      \
+    persistent(elem, B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point, cfg->max_Cin,   \
+               cfg->max_Cout)
+int conv3p_forward_cached_f32(FWD_ARGS(float), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return forward_impl<float>(FWD_PASS, CACHE_WHERE(4), stream);
+}
+int conv3p_forward_cached_f64(FWD_ARGS(double), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return forward_impl<double>(FWD_PASS, CACHE_WHERE(8), stream);
+}
+int conv3p_backward_cached_f32(BWD_ARGS(float), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return backward_impl<float>(BWD_PASS, CACHE_WHERE(4), stream);
+}
+int conv3p_backward_cached_f64(BWD_ARGS(double), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return backward_impl<double>(BWD_PASS, CACHE_WHERE(8), stream);
+}
+
 int conv3p_neighbor_count_f32(const float *points, const int32_t *stride_xyz, float voxel_size, int B,
                               int N, int fz, int fy, int fx, int32_t *count, void *workspace,
                               size_t workspace_bytes, void *stream)
@@ -466,7 +680,6 @@ int conv3p_selu_grad_f64(const double *y, const double *dy, double *dx, size_t n
 {
     return selu_grad_impl<double>(y, dy, nullptr, dx, n, stream);
 }
-
 int conv3p_selu_grad_add_f32(const float *y, const float *dy_a, const float *dy_b, float *dx, size_t n,
                              void *stream)
 {
@@ -521,7 +734,7 @@ const char *conv3p_status_string(int status)
     switch (status) {
     case CONV3P_OK: return "ok";
     case CONV3P_ERR_INVALID_ARGUMENT: return "invalid argument";
-    case CONV3P_ERR_WORKSPACE: return "workspace null, misaligned or too small";
+    case CONV3P_ERR_WORKSPACE: return "workspace / cache null, misaligned or too small";
     case CONV3P_ERR_UNSUPPORTED: return "unsupported configuration";
     case CONV3P_ERR_LAUNCH: return "HIP launch error";
     case CONV3P_ERR_NO_DEVICE: return "no HIP device";

@@ -294,14 +294,19 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
 // fwd_tap : tap of ii inside j's box                      (forward,  .cpp:280-290)
 // bwd_tap : tap of j inside ii's box, kNoTap for a hole   (backward, .cpp:662-677)
 // q       : lane (0..63) of the centre inside its query tile
-// All pairs of a query tile are contiguous (one segment per tile).  Entries whose exact test
-// failed (pre-filter false positives) carry fwd_tap = kNoTap and are skipped by the consumers.
+// All pairs of a query tile are contiguous (one segment per tile), centre-major inside.  Entries
+// whose exact test failed (pre-filter false positives) carry fwd_tap = kNoTap and are skipped by
+// the consumers.  finalise_kernel adds the two normalisers once the populations of ALL points
+// are known: rcp_fwd = 1/count[j][fwd], rcp_bwd = 1/count[ii][bwd] (0 for a hole or an empty
+// tap, the reference's `count == 0` skip, .cpp:679).
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kNoTap = 0xFFFu;
 constexpr uint32_t kSegOverflow = 0xFFFFFFFFu;
-struct PairEntry {
+struct __attribute__((aligned(16))) PairEntry {
     uint32_t cand;
     uint32_t code;
+    float rcp_fwd;   // 1 / population of tap fwd of the centre   (finalise_kernel; fp32 ops only)
+    float rcp_bwd;   // 1 / population of tap bwd of the neighbour, 0 when the pair contributes nothing
 };
 __device__ __forceinline__ uint32_t pair_code(uint32_t fwd, uint32_t bwd, uint32_t q) { return fwd | (bwd << 12) | (q << 24); }
 __device__ __forceinline__ uint32_t code_fwd(uint32_t c) { return c & 0xFFFu; }

@@ -10,7 +10,43 @@
 
 #include "conv3p_device.hpp"
 
+#ifndef CONV3P_ABLATE
+#define CONV3P_ABLATE 0   // developer ablation switch (tools/ablate.sh); 0 in every shipped build
+#endif
+
 namespace conv3p {
+
+// ---------------------------------------------------------------------------------
+// Neighbour cache control (device side).  A cache buffer holds, per cloud b,
+//   hash[b]     64-bit content hash of the cloud's raw coordinates (prep_sort_kernel)
+//   version[b]  bumped by prep_sort_kernel whenever hash[b] changes (single writer: one
+//               workgroup per cloud)
+// and per search slot (one slot = one stencil: filter extents, stride, voxel)
+//   built_version[b], built_tag[b]   what the slot's pair lists of cloud b were built from
+//   rebuilt[b]                       == epoch of the call that rebuilt them (search -> finalise)
+//   cursor[b]                        pair-slot allocator of cloud b's region
+// A slot is valid for cloud b iff built_version[b] == version[b] && built_tag[b] == tag.
+// Nothing is ever read back by the host: every decision is taken on the device, so a stale
+// or recycled buffer can only cost a rebuild, never a wrong result.
+// force != 0 (the stateless entry points): ignore the buffer's history and rebuild.
+// ---------------------------------------------------------------------------------
+struct CacheCtl {
+    unsigned long long *hash;        // [B]
+    uint32_t *version;               // [B]
+    uint32_t *built_version;         // [B] of the slot in use
+    unsigned long long *built_tag;   // [B]
+    uint32_t *rebuilt;               // [B]
+    uint32_t *cursor;                // [B]
+    unsigned long long tag;
+    uint32_t epoch;
+    uint32_t pairs_per_cloud;
+    int force;
+};
+
+__device__ __forceinline__ bool slot_valid(const CacheCtl &cc, int b)
+{
+    return !cc.force && cc.built_version[b] == cc.version[b] && cc.built_tag[b] == cc.tag;
+}
 
 // ---------------------------------------------------------------------------------
 // prep: one wavefront per tile.  Identity order (tile t = points [64t, 64t+64)).
@@ -20,9 +56,14 @@ namespace conv3p {
 template <typename T>
 __global__ __launch_bounds__(256) void prep_kernel(const T *__restrict__ points, int N, int ntiles,
                                                    PointRec<T> *__restrict__ pts,
-                                                   T *__restrict__ boxes, uint32_t *__restrict__ cursor)
+                                                   T *__restrict__ boxes, CacheCtl cc)
 {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *cursor = 0;
+    // clouds too large for the LDS sort are never cached: bump the version every call
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cc.version[blockIdx.y] += 1;
+        cc.hash[blockIdx.y] = 0;
+        cc.cursor[blockIdx.y] = 0;
+    }
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -58,7 +99,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const T *__restrict__ points,
 // sorted points is a tile with a tight bounding box, which is what makes the candidate-tile
 // culling of for_each_box_hit effective.  The order only affects speed: neighbour decisions
 // are taken per pair with the reference's arithmetic, whatever the tiling.
-// Requires npad (power of two >= N) * 8 bytes of LDS: N <= 16384.  Larger clouds use
+// Requires npad (power of two >= N) * 8 + 256 bytes of LDS: N <= 16384.  Larger clouds use
 // prep_kernel (identity order).
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t spread10(uint32_t v)
@@ -74,9 +115,8 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)
 template <typename T>
 __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ points, int N, int ntiles,
                                                          int npad, PointRec<T> *__restrict__ pts,
-                                                         T *__restrict__ boxes, uint32_t *__restrict__ cursor)
+                                                         T *__restrict__ boxes, CacheCtl cc)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     __shared__ float red[6][16];
@@ -84,6 +124,39 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
     const int lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const T *cloud = points + (size_t)b * N * 3;
+
+    // ---- content hash of the raw coordinates (order-sensitive per element, order-free combination)
+    unsigned long long *hred = reinterpret_cast<unsigned long long *>(smem + (size_t)npad * 8);   // [16] + flag
+    {
+        unsigned long long h = 0;
+        const int nwords = N * 3 * (int)(sizeof(T) / 4);
+        const uint32_t *raw = reinterpret_cast<const uint32_t *>(cloud);
+        for (int i = tid; i < nwords; i += nthr) {
+            unsigned long long x = ((unsigned long long)(uint32_t)i << 32) | raw[i];
+            x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+            h += x;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+        if (lane == 0) hred[wave] = h;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0;
+            for (int w = 0; w < (nthr >> 6); ++w) t += hred[w];
+            t |= 1ull;   // never 0: a zero-filled buffer is always stale
+            const bool same = !cc.force && cc.hash[b] == t;
+            if (!same) {
+                cc.hash[b] = t;
+                cc.version[b] += 1;
+            }
+            // the slot about to be used must allocate from an empty region if it is going to rebuild
+            const bool valid = same && cc.built_version[b] == cc.version[b] && cc.built_tag[b] == cc.tag;
+            if (!valid) cc.cursor[b] = 0;
+            hred[16] = same ? 1ull : 0ull;
+        }
+        __syncthreads();
+        if (hred[16] != 0) return;   // sorted records and tile boxes of this cloud are still current
+    }
 
     // bounding cube (float precision is enough: the order is a performance hint only)
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -234,9 +307,8 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                                                      const T *__restrict__ boxes, Stencil<T> st, int N,
                                                      int ntiles, int gtiles, int ngroups, BlockMap bm,
                                                      int32_t *__restrict__ count,
-                                                     PairEntry *__restrict__ pairs, uint32_t cap,
-                                                     uint32_t *__restrict__ cursor, uint2 *__restrict__ segs,
-                                                     uint2 *__restrict__ qsegs)
+                                                     PairEntry *__restrict__ pairs, CacheCtl cc,
+                                                     uint2 *__restrict__ segs, uint2 *__restrict__ qsegs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
@@ -258,11 +330,16 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
     off += align16((size_t)kWavesPerBlock * 192 * 4);
     uint32_t *stream = reinterpret_cast<uint32_t *>(smem + off) + wave * 256;   // [0..127] pair, [128..255] slot
 
-    build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
-
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;   // uniform for the workgroup
+    if (pairs != nullptr) {
+        if (slot_valid(cc, b)) return;        // this cloud's lists are current (uniform)
+        if (threadIdx.x == 0) cc.rebuilt[b] = cc.epoch;
+    }
+    build_tapmap(tapmap, st.full, st.step, st.maxfull);
+    for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
+    const uint32_t cap = cc.pairs_per_cloud;
+    const uint32_t region = (uint32_t)b * cap;   // first pair slot of this cloud's region
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
     const T *cloud_box = boxes + (size_t)b * ntiles * 6;
     Query<T> q;
@@ -306,8 +383,9 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
             uint32_t base = 0, ok = 0;
             if (pairs != nullptr) {
                 if (lane == 0) {
-                    base = L ? atomicAdd(cursor, (uint32_t)L) : 0u;
+                    base = L ? atomicAdd(&cc.cursor[b], (uint32_t)L) : 0u;
                     ok = (base <= cap && (uint32_t)L <= cap - base) ? 1u : 0u;
+                    base += region;
                     segs[((size_t)b * ntiles + qt) * ngroups + g] =
                         ok ? make_uint2(base, (uint32_t)L) : make_uint2(0u, kSegOverflow);
                     misc[4] = base;
@@ -358,6 +436,8 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                         PairEntry pe;
                         pe.cand = (uint32_t)v.idx;
                         pe.code = pair_code(fwd, bwd, ql);
+                        pe.rcp_fwd = 0.0f;
+                        pe.rcp_bwd = 0.0f;
                         pairs[(size_t)gbase + stream[128 + lane]] = pe;
                     }
                 }
@@ -405,6 +485,47 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
             int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
             for (int f = lane; f < st.ntap; f += 64) row[f] = (int32_t)cnt[f * kCntStride + qq];
         }
+}
+
+// ---------------------------------------------------------------------------------
+// finalise: once every population is known, store the two normalisers of each pair
+// (dense, thread = pair).  rcp = 1 / (float)count is the correctly rounded IEEE quotient.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__restrict__ pts,
+                                                       const int32_t *__restrict__ count, int N, int ntiles,
+                                                       int ngroups, int ntap, BlockMap bm,
+                                                       PairEntry *__restrict__ pairs,
+                                                       const uint2 *__restrict__ segs, CacheCtl cc)
+{
+    __shared__ int32_t qorig[64];
+    int b, qt;
+    if (!block_to_cloud(bm, b, qt)) return;
+    if (cc.rebuilt[b] != cc.epoch) return;   // search_kernel did not rebuild this cloud in this call
+    if (threadIdx.x == 0) {                  // commit (every workgroup of the cloud writes the same values)
+        cc.built_version[b] = cc.version[b];
+        cc.built_tag[b] = cc.tag;
+    }
+    if (threadIdx.x < 64) qorig[threadIdx.x] = pts[((size_t)b * ntiles + qt) * kTile + threadIdx.x].idx;
+    __syncthreads();
+    const int32_t *cnt_cloud = count + (size_t)b * N * ntap;
+    for (int g = 0; g < ngroups; ++g) {
+        const uint2 sg = segs[((size_t)b * ntiles + qt) * ngroups + g];
+        if (sg.y == kSegOverflow) continue;
+        PairEntry *pe = pairs + sg.x;
+        for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
+            const uint32_t code = pe[e].code, fwd = code_fwd(code), bwd = code_bwd(code);
+            if (fwd == kNoTap) continue;
+            const int cf = cnt_cloud[(size_t)qorig[code_q(code)] * ntap + fwd];
+            float rb = 0.0f;
+            if (bwd != kNoTap) {
+                const int cb = cnt_cloud[(size_t)pe[e].cand * ntap + bwd];
+                if (cb != 0) rb = 1.0f / (float)cb;                                  // .cpp:678-679
+            }
+            pe[e].rcp_fwd = 1.0f / (float)cf;
+            pe[e].rcp_bwd = rb;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -467,8 +588,8 @@ __global__ __launch_bounds__(256) void forward_kernel(
         for (int c = 0; c < COUT; ++c) acc[c] = (T)0;
     }
     // centre = lane `ql` (always this lane on the small path)
-    auto accumulate = [&](uint32_t cand, uint32_t f, uint32_t ql) {
-        const T rcp = (T)1 / (T)cnt[f * kCntStride + ql];                // 1 / (T)fsize, .cpp:483
+    auto accumulate = [&](uint32_t cand, uint32_t f, uint32_t ql, T rcp) {
+        // rcp = 1 / (T)fsize (.cpp:483): from the pair record (fp32) or from the populations in LDS
         const T *xr = in_cloud + (size_t)cand * cin;
         if constexpr (kSmall) {
             T xs[CIN];
@@ -499,12 +620,15 @@ __global__ __launch_bounds__(256) void forward_kernel(
                 // lane = centre; the four waves take every 4th pair of the centre's list
                 const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + lane];
                 const PairEntry *pe = pairs + sg.x;
+                PairEntry cur = pe[wave < sg.y ? wave : 0];
                 for (uint32_t i = wave; __any(i < sg.y); i += kWavesPerBlock) {
+                    const uint32_t nx = i + kWavesPerBlock;
+                    const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
                     if (i < sg.y) {
-                        const PairEntry en = pe[i];
-                        const uint32_t f = code_fwd(en.code);
-                        if (f != kNoTap) accumulate(en.cand, f, (uint32_t)lane);
+                        const uint32_t f = code_fwd(cur.code);
+                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)lane, (T)cur.rcp_fwd);
                     }
+                    cur = nxt;
                 }
             } else {
                 const uint2 sg = segs[tile_id * ngroups + g];
@@ -512,7 +636,7 @@ __global__ __launch_bounds__(256) void forward_kernel(
                 for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
                     const PairEntry en = pe[e];
                     const uint32_t f = code_fwd(en.code);
-                    if (f != kNoTap) accumulate(en.cand, f, code_q(en.code));
+                    if (f != kNoTap) accumulate(en.cand, f, code_q(en.code), (T)1 / (T)cnt[f * kCntStride + code_q(en.code)]);
                 }
             }
         }
@@ -522,7 +646,9 @@ __global__ __launch_bounds__(256) void forward_kernel(
         Query<T> q;
         make_query(q, me, st);
         for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
-                          [&](const PointRec<T> &v, int f) { accumulate((uint32_t)v.idx, (uint32_t)f, (uint32_t)lane); });
+                          [&](const PointRec<T> &v, int f) {
+            accumulate((uint32_t)v.idx, (uint32_t)f, (uint32_t)lane, (T)1 / (T)cnt[f * kCntStride + lane]);
+        });
     }
 
     if constexpr (kSmall) {
@@ -617,10 +743,13 @@ __global__ __launch_bounds__(256) void backward_kernel(
         T *dx_cloud = grad_input + (size_t)b * N * cin;
         // phase A.  Small path: lane = centre `ql` == lane; wave w owns the taps f' == w (mod 4), so
         // every G element has exactly one writer and plain LDS read-modify-write is race-free.
-        auto accumulate = [&](uint32_t cand, uint32_t fb, uint32_t ql) {
-            const int cn = cnt_cloud[(size_t)cand * st.ntap + fb];
-            if (cn == 0) return;                                              // .cpp:679
-            const T rcp = (T)1 / (T)cn;
+        auto accumulate = [&](uint32_t cand, uint32_t fb, uint32_t ql, T rcp) {
+            // rcp = 1 / count of tap fb of the neighbour (.cpp:678); <= 0 asks for a lookup here
+            if (!(rcp > (T)0)) {
+                const int cn = cnt_cloud[(size_t)cand * st.ntap + fb];
+                if (cn == 0) return;                                          // .cpp:679
+                rcp = (T)1 / (T)cn;
+            }
             const T *dyr = dy_cloud + (size_t)cand * cout;
             if constexpr (kSmall) {
                 T *grow = G + ((size_t)fb * COUT) * kCntStride + ql;
@@ -652,15 +781,19 @@ __global__ __launch_bounds__(256) void backward_kernel(
         if (!overflow) {
             for (int g = 0; g < ngroups; ++g) {
                 if constexpr (kSmall) {
+                    if (CONV3P_ABLATE & 1) continue;
                     const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + lane];
                     const PairEntry *pe = pairs + sg.x;
+                    PairEntry cur = pe[0];
                     for (uint32_t i = 0; __any(i < sg.y); ++i) {
+                        const PairEntry nxt = pe[i + 1 < sg.y ? i + 1 : 0];   // prefetch the next record
                         if (i < sg.y) {
-                            const PairEntry en = pe[i];
-                            const uint32_t fb = code_bwd(en.code);
-                            if (code_fwd(en.code) != kNoTap && fb != kNoTap && (int)(fb & (kWavesPerBlock - 1)) == wave)
-                                accumulate(en.cand, fb, (uint32_t)lane);
+                            const uint32_t fb = code_bwd(cur.code);
+                            // rcp_bwd == 0: false positive, hole, or empty tap -> contributes nothing
+                            if (cur.rcp_bwd > 0.0f && (int)(fb & (kWavesPerBlock - 1)) == wave)
+                                accumulate(cur.cand, fb, (uint32_t)lane, (T)cur.rcp_bwd);
                         }
+                        cur = nxt;
                     }
                 } else {
                     const uint2 sg = segs[tile_id * ngroups + g];
@@ -668,7 +801,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
                         const PairEntry en = pe[e];
                         const uint32_t fb = code_bwd(en.code);
-                        if (code_fwd(en.code) != kNoTap && fb != kNoTap) accumulate(en.cand, fb, code_q(en.code));
+                        if (code_fwd(en.code) != kNoTap && fb != kNoTap) accumulate(en.cand, fb, code_q(en.code), (T)0);
                     }
                 }
             }
@@ -683,7 +816,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                               kSmall ? 1 : kWavesPerBlock, [&](const PointRec<T> &v, int) {
                 const uint32_t fb = backward_tap(q.p, v, st, tapmap);
                 if (fb != kNoTap && (!kSmall || (int)(fb & (kWavesPerBlock - 1)) == wave))
-                    accumulate((uint32_t)v.idx, fb, (uint32_t)lane);
+                    accumulate((uint32_t)v.idx, fb, (uint32_t)lane, (T)0);
             });
         }
     }
@@ -692,7 +825,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
         __syncthreads();
         // ---- phase B: dW rows.  thread = row (f,c); X tile read with wave-uniform addresses.
         T *slot = partials + (size_t)blockIdx.x * nw;
-        for (int row = threadIdx.x; row < nrows; row += blockDim.x) {
+        for (int row = threadIdx.x; row < ((CONV3P_ABLATE & 2) ? 0 : nrows); row += blockDim.x) {
             T acc[CIN];
 #pragma unroll
             for (int k = 0; k < CIN; ++k) acc[k] = (T)0;
@@ -710,7 +843,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
         T dx[CIN];
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
-        for (int row = wave; row < nrows; row += kWavesPerBlock) {
+        for (int row = wave; row < ((CONV3P_ABLATE & 4) ? 0 : nrows); row += kWavesPerBlock) {
             const T g = G[(size_t)row * kCntStride + lane];
             if (!__any(g != (T)0)) continue;
             const T *wr = wt + (size_t)row * CIN;

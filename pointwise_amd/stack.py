@@ -24,8 +24,13 @@ HIDDEN = 9
 
 
 class Conv3pStack:
-    def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234):
-        """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers)."""
+    def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234,
+                 use_cache=True):
+        """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers).
+        use_cache: keep the geometry (sorted points, populations, neighbour lists) of each layer's stencil in
+        a NeighborCache so that the search runs once per (points, stride) instead of once per op call."""
+        self.use_cache = use_cache
+        self._cache = None
         self.device = torch.device(device)
         self.dtype = dtype
         self.num_class = num_class
@@ -48,16 +53,27 @@ class Conv3pStack:
             o += n
         self._saved = None
 
+    def _cache_for(self, points):
+        if not self.use_cache:
+            return None
+        B, N = points.shape[0], points.shape[1]
+        cmax = max(max(ci, co) for ci, co, _ in self.layers)
+        if self._cache is None or not self._cache.fits(B, N, points.dtype, points.device, 27, cmax, cmax):
+            self._cache = op.NeighborCache(B, N, points.dtype, points.device, slots=len(self.layers), max_taps=27,
+                                           max_cin=cmax, max_cout=cmax)
+        return self._cache
+
     def forward(self, points, features):
+        cache = self._cache_for(points)
         acts, x = [], features
         for li in range(4):
             _, _, s = self.layers[li]
-            x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL))
+            x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL, cache=cache))
             acts.append(x)
         concat = None
         if self.num_class is not None:
             concat = torch.cat(acts, dim=2)
-            acts.append(op.selu(op.conv3p(points, concat, self.filters[4], (1, 1, 1), VOXEL)))
+            acts.append(op.selu(op.conv3p(points, concat, self.filters[4], (1, 1, 1), VOXEL, cache=cache)))
         self._saved = (points, features, acts, concat)
         return acts
 
@@ -65,10 +81,11 @@ class Conv3pStack:
         """upstream: classification -> list of 4 tensors dL/d(act_l) (the slices of dL/dconcat);
         segmentation -> [dL/dlogits_act].  Returns (dL/dfeatures, fused weight-gradient buffer)."""
         points, features, acts, concat = self._saved
+        cache = self._cache_for(points)
         if self.num_class is not None:
             g = op.selu_grad(acts[4], upstream[0])
             dconcat, _ = op.conv3p_grad(g, points, concat, self.filters[4], (1, 1, 1), VOXEL,
-                                        grad_filter_out=self.grad_views[4])
+                                        grad_filter_out=self.grad_views[4], cache=cache)
             ext = [dconcat[:, :, HIDDEN * i:HIDDEN * (i + 1)].contiguous() for i in range(4)]
         else:
             ext = list(upstream)
@@ -78,7 +95,7 @@ class Conv3pStack:
             g = op.selu_grad(acts[li], ext[li], carry)
             x_in = acts[li - 1] if li > 0 else features
             carry, _ = op.conv3p_grad(g, points, x_in, self.filters[li], (s, s, s), VOXEL,
-                                      grad_filter_out=self.grad_views[li])
+                                      grad_filter_out=self.grad_views[li], cache=cache)
         return carry, self.fused_grad
 
 

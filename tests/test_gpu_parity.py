@@ -269,3 +269,70 @@ def test_layer_stacks_match_oracle(dev, num_class, cin, kind):
         assert rel_err(a.cpu().numpy(), r) <= 2e-5
     assert rel_err(dx.cpu().numpy(), ref_dx) <= 5e-5
     assert rel_err(fused.cpu().numpy(), ref_fused) <= 5e-5
+
+
+# ------------------------------------------------------------------ neighbour cache (content-validated reuse)
+def _both(dev, cache, P, X, W, dY, s):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tp, tx, tw, tdy = t(P), t(X), t(W), t(dY)
+    y = op.conv3p(tp, tx, tw, s, VOX, cache=cache)
+    dx, dw = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=cache)
+    return y, dx, dw
+
+
+def test_cache_matches_stateless_bitwise_and_tracks_content(dev):
+    """Same kernels, same order: cached results are bit-identical to the stateless ones; changing the clouds
+    (same buffer shapes, even the same device pointers) is detected on the device and triggers a rebuild."""
+    B, N = 4, 512
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=2, max_taps=27, max_cin=9, max_cout=9)
+    P1, X, W, dY = make_case("modelnet", B, N, 9, 9, seed=800)
+    P2 = make_case("modelnet", B, N, 9, 9, seed=801)[0]
+    P3 = P1.copy()
+    P3[2] = P2[2]                                       # only cloud 2 differs from P1
+    tp = torch.from_numpy(P1).to(dev)                   # ONE device buffer, contents rewritten in place
+    tx, tw, tdy = [torch.from_numpy(a).to(dev) for a in (X, W, dY)]
+    for P in (P1, P1, P2, P3, P1):
+        tp.copy_(torch.from_numpy(P))
+        for s in ((2, 2, 2), (1, 1, 1), (2, 2, 2)):
+            y_c = op.conv3p(tp, tx, tw, s, VOX, cache=cache)
+            dx_c, dw_c = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=cache)
+            y_s = op.conv3p(tp, tx, tw, s, VOX)
+            dx_s, dw_s = op.conv3p_grad(tdy, tp, tx, tw, s, VOX)
+            assert torch.equal(y_c, y_s) and torch.equal(dx_c, dx_s) and torch.equal(dw_c, dw_s)
+    y_ref = oracle.forward(P1, X, W, (2, 2, 2), VOX)
+    assert rel_err(y_c.cpu().numpy(), y_ref) <= 1e-5
+
+
+def test_cache_slot_eviction(dev):
+    """More stencils than slots: least-recently-used slots are rebuilt, results stay exact."""
+    B, N = 2, 300
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=2, max_taps=27, max_cin=9, max_cout=9)
+    P, X, W, dY = make_case("room", B, N, 9, 9, seed=810)
+    for rep in range(2):
+        for st in (1, 2, 3, 4, 2, 1):
+            s = (st, st, st)
+            y, dx, dw = _both(dev, cache, P, X, W, dY, s)
+            assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, s, VOX)) <= 1e-5
+            dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, VOX)
+            assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
+
+
+def test_cache_garbage_buffer_is_harmless(dev):
+    """A cache whose bytes are garbage (never zero-filled, or recycled) can only cost a rebuild."""
+    B, N = 2, 256
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=3, max_cout=9)
+    cache.buf.random_(0, 255)
+    P, X, W, dY = make_case("cube", B, N, 3, 9, seed=820)
+    y, dx, dw = _both(dev, cache, P, X, W, dY, (1, 1, 1))
+    assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, (1, 1, 1), VOX)) <= 1e-5
+    dx_ref, dw_ref = oracle.backward(dY, P, X, W, (1, 1, 1), VOX)
+    assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
+
+
+def test_results_are_bitwise_reproducible(dev):
+    """No floating-point atomics on the register-resident paths: two runs give identical bits."""
+    P, X, W, dY = make_case("modelnet", 4, 1024, 9, 9, seed=830)
+    a = _both(dev, None, P, X, W, dY, (2, 2, 2))
+    b = _both(dev, None, P, X, W, dY, (2, 2, 2))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

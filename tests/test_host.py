@@ -35,7 +35,8 @@ def test_load_binds_and_reports_version():
     assert _lib.status_string(0) == "ok"
     assert "workspace" in _lib.status_string(_lib.ERR_WORKSPACE)
     assert lib.conv3p_profile_kinds() >= 5
-    assert lib.conv3p_profile_name(2).decode() == "forward_kernel"
+    names = [lib.conv3p_profile_name(k).decode() for k in range(lib.conv3p_profile_kinds())]
+    assert {"prep_kernel", "search_kernel", "forward_kernel", "backward_kernel"} <= set(names)
 
 
 def test_workspace_bytes():
@@ -55,6 +56,19 @@ def test_workspace_bytes():
     # cfg5 per GPU (B=16, N=8192, 128->256): sizes are 64-bit, nothing overflows
     big = f(_lib.PASS_BACKWARD, 4, 16, 8192, 128, 256, 3, 3, 3)
     assert big > 16 * 8192 * 27 * 4
+
+
+def test_cache_bytes():
+    lib = _lib.load()
+    cfg = _lib.CacheConfig(4, 27, 0, 9, 9)
+    one = lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(1, 27, 0, 9, 9)))
+    four = lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(cfg))
+    assert 0 < one < four and four % 256 == 0
+    assert four >= 4 * 32 * 2048 * (27 * 4 + 128 * 16)              # populations + pair records per slot
+    assert lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(0, 27, 0, 9, 9))) == 0
+    assert lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(4, 5000, 0, 9, 9))) == 0
+    assert lib.conv3p_cache_bytes(2, 32, 2048, ctypes.byref(cfg)) == 0
+    assert lib.conv3p_cache_forget(None) == _lib.OK
 
 
 def test_invalid_arguments_without_touching_the_gpu():
