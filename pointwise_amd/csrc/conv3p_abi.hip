@@ -339,11 +339,11 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    const size_t lds = lds_common(st) +
-                       (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) +
-                                     a16((size_t)64 * CI * sizeof(T)) + a16((size_t)kWavesPerBlock * CI * 64 * sizeof(T))
-                               : 0) +
-                       256 + a16((size_t)kWavesPerBlock * 192 * 4);
+    // reduce buffer [4][CI][64] aliases { Wt | X tile | SoA }
+    size_t tail = (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)64 * CI * sizeof(T)) : 0) + a16((size_t)kWavesPerBlock * 192 * 4);
+    const size_t red = CI > 0 ? a16((size_t)kWavesPerBlock * CI * 64 * sizeof(T)) : 0;
+    if (tail < red) tail = red;
+    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) : 0) + 256 + tail;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_BACKWARD, c.s);

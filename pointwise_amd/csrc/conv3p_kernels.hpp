@@ -531,9 +531,9 @@ __global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__rest
 // ---------------------------------------------------------------------------------
 // forward accumulate: out[i,c] = sum over pairs of W[f,k,c] * x[j,k] / count[i,f]  (.cpp:480-494)
 // One workgroup = one query tile; threads stride over the tile's pair segment (lane = pair).
-// Small path (CIN/COUT compile-time): lane = centre, the four waves take every 4th pair of the
-// centre's list; filter and own populations in LDS; output row in registers, the four partial
-// rows summed through LDS in a fixed order (bitwise reproducible).  Generic path: thread = pair,
+// Small path (CIN/COUT compile-time): each wave owns 16 centres, the 4 lanes {c, c+16, c+32, c+48}
+// walk centre c's list 4 records at a time; filter in LDS, output row in registers, the 4 partial
+// rows combined by a fixed shuffle butterfly (bitwise reproducible).  Generic path: thread = pair,
 // global atomics into the zeroed output.
 // A segment marked kSegOverflow makes the workgroup search its query tile itself.
 // ---------------------------------------------------------------------------------
@@ -560,7 +560,8 @@ __global__ __launch_bounds__(256) void forward_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
-    T *red = reinterpret_cast<T *>(smem + off);   // [4][COUT][64], small path only
+    T *red = reinterpret_cast<T *>(smem + off);   // [4][COUT][64], overflow path only
+    const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense path: centre and sub-lane of this thread
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     if (kSmall)
@@ -617,16 +618,17 @@ __global__ __launch_bounds__(256) void forward_kernel(
     if (!overflow) {
         for (int g = 0; g < ngroups; ++g) {
             if constexpr (kSmall) {
-                // lane = centre; the four waves take every 4th pair of the centre's list
-                const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + lane];
+                // wave w owns the centres 16w..16w+15; the 4 lanes {c, c+16, c+32, c+48} share centre c and
+                // read 4 consecutive pair records per step (64 contiguous bytes)
+                const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                 const PairEntry *pe = pairs + sg.x;
-                PairEntry cur = pe[wave < sg.y ? wave : 0];
-                for (uint32_t i = wave; __any(i < sg.y); i += kWavesPerBlock) {
-                    const uint32_t nx = i + kWavesPerBlock;
+                PairEntry cur = pe[sub < sg.y ? sub : 0];
+                for (uint32_t i = sub; __any(i < sg.y); i += 4) {
+                    const uint32_t nx = i + 4;
                     const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
                     if (i < sg.y) {
                         const uint32_t f = code_fwd(cur.code);
-                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)lane, (T)cur.rcp_fwd);
+                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)cq, (T)cur.rcp_fwd);
                     }
                     cur = nxt;
                 }
@@ -652,16 +654,29 @@ __global__ __launch_bounds__(256) void forward_kernel(
     }
 
     if constexpr (kSmall) {
-        // fixed-order sum of the per-wave partial rows
+        if (!overflow) {
+            // the 4 sub-lanes of a centre hold partial rows: fixed-order butterfly, lane `cq & 15` of
+            // sub-lane 0 writes the row
+            const int orig = qorig[cq];
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
-        __syncthreads();
-        for (int e = threadIdx.x; e < COUT * 64; e += blockDim.x) {
-            const int c = e >> 6;   // e & 63 == lane
-            T s = red[((size_t)0 * COUT + c) * 64 + lane];
+            for (int c = 0; c < COUT; ++c) {
+                T v = acc[c];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (sub == 0 && orig >= 0) out_cloud[(size_t)orig * COUT + c] = v;
+            }
+        } else {
+            // overflow path ran lane = centre in every wave: fixed-order sum of the per-wave partial rows
 #pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) s += red[((size_t)w * COUT + c) * 64 + lane];
-            if (me.idx >= 0) out_cloud[(size_t)me.idx * COUT + c] = s;
+            for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
+            __syncthreads();
+            for (int e = threadIdx.x; e < COUT * 64; e += blockDim.x) {
+                const int c = e >> 6;   // e & 63 == lane
+                T sum = red[((size_t)0 * COUT + c) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * COUT + c) * 64 + lane];
+                if (me.idx >= 0) out_cloud[(size_t)me.idx * COUT + c] = sum;
+            }
         }
     }
 }
@@ -672,15 +687,16 @@ __global__ __launch_bounds__(256) void forward_kernel(
 //   count = population of tap f' of ii, pair skipped when 0 (.cpp:678-679),
 //   g[c] = dY[ii,c] / count,  dX[j,k] += g[c] W[f',k,c],  dW[f',k,c] += g[c] X[j,k].
 // Small path (one workgroup = one query tile):
-//   phase A  lane = centre j walking its own pair list; wave w owns the taps f' == w (mod 4):
-//            G[(f',c)][j] += dY[ii,c] * (1/count)   (LDS [row][65], one writer per element, no atomics)
+//   phase A  each wave owns 16 centres; the 4 lanes {c, c+16, c+32, c+48} walk centre c's pair list 4
+//            records per step:  G[(f',c)][j] += dY[ii,c] * (1/count)   (LDS [row][65]; sub-lanes that
+//            meet on one tap take turns in a fixed order -> no atomics, reproducible)
 //   phase B  thread = row (f',c):  dW[f',k,c] = sum_j G[row][j] * X[j,k]  -> this workgroup's
 //            partial slot (X tile broadcast from LDS)
 //   phase C  lane = centre j, waves split the rows:  dX[j,k] = sum_row G[row][j] * W[row][k],
 //            per-wave partial rows summed through LDS in fixed order.
 //   No floating-point atomics anywhere on this path: results are bitwise reproducible.
 // Generic path: lane = pair, global atomics into zeroed dX and partial slot 0.
-// LDS small: tapmap | Wt [F*COUT][CIN] | G [F*COUT][65] | X tile [64][CIN] | centres | SoA | reduce
+// LDS small: tapmap | G [F*COUT][65] | qorig | { Wt [F*COUT][CIN] | X tile [64][CIN] | SoA }  (reduce aliases {})
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void backward_kernel(
@@ -698,18 +714,19 @@ __global__ __launch_bounds__(256) void backward_kernel(
     size_t off = align16((size_t)3 * st.maxfull * 2);
     const size_t nw = (size_t)st.ntap * cin * cout;
     const int nrows = st.ntap * cout;
-    T *wt = reinterpret_cast<T *>(smem + off);        // Wt[row][k], row = f*COUT + c
-    if (kSmall) off += align16(nw * sizeof(T));
     T *G = reinterpret_cast<T *>(smem + off);         // G[row][65]
     if (kSmall) off += align16((size_t)nrows * kCntStride * sizeof(T));
-    T *xt = reinterpret_cast<T *>(smem + off);        // X tile [64][CIN]
-    if (kSmall) off += align16((size_t)64 * cin * sizeof(T));
     int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
     off += 256;
+    T *red = reinterpret_cast<T *>(smem + off);       // [4][CIN][64]: ALIASES wt | xt | soa (used after them)
+    T *wt = reinterpret_cast<T *>(smem + off);        // Wt[row][k], row = f*COUT + c
+    if (kSmall) off += align16(nw * sizeof(T));
+    T *xt = reinterpret_cast<T *>(smem + off);        // X tile [64][CIN]
+    if (kSmall) off += align16((size_t)64 * cin * sizeof(T));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
-    T *red = reinterpret_cast<T *>(smem + off);       // [4][CIN][64], small path only
+    const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense phase A: centre and sub-lane
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     if (kSmall) {
@@ -754,7 +771,10 @@ __global__ __launch_bounds__(256) void backward_kernel(
             if constexpr (kSmall) {
                 T *grow = G + ((size_t)fb * COUT) * kCntStride + ql;
 #pragma unroll
-                for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += dyr[c] * rcp;
+                for (int c = 0; c < COUT; ++c) {
+                    if (CONV3P_ABLATE & 16) { asm volatile("" :: "v"(dyr[c] * rcp)); }
+                    else grow[c * kCntStride] += dyr[c] * rcp;
+                }
             } else {
                 const int jo = qorig[ql];
                 const T *wf = filter + (size_t)fb * cin * cout;
@@ -782,16 +802,38 @@ __global__ __launch_bounds__(256) void backward_kernel(
             for (int g = 0; g < ngroups; ++g) {
                 if constexpr (kSmall) {
                     if (CONV3P_ABLATE & 1) continue;
-                    const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + lane];
+                    // wave w owns the centres 16w..16w+15; lanes {c, c+16, c+32, c+48} walk centre c's list
+                    // 4 records per step.  Two sub-lanes of a centre may hit the same tap in one step: the
+                    // lower sub-lane goes first (fixed order), the other retries -> race-free, reproducible.
+                    const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                     const PairEntry *pe = pairs + sg.x;
-                    PairEntry cur = pe[0];
-                    for (uint32_t i = 0; __any(i < sg.y); ++i) {
-                        const PairEntry nxt = pe[i + 1 < sg.y ? i + 1 : 0];   // prefetch the next record
-                        if (i < sg.y) {
-                            const uint32_t fb = code_bwd(cur.code);
-                            // rcp_bwd == 0: false positive, hole, or empty tap -> contributes nothing
-                            if (cur.rcp_bwd > 0.0f && (int)(fb & (kWavesPerBlock - 1)) == wave)
-                                accumulate(cur.cand, fb, (uint32_t)lane, (T)cur.rcp_bwd);
+                    PairEntry cur = pe[sub < sg.y ? sub : 0];
+                    for (uint32_t i = sub; __any(i < sg.y); i += 4) {
+                        const uint32_t nx = i + 4;
+                        const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
+                        // rcp_bwd == 0: false positive, hole, or empty tap -> contributes nothing
+                        bool pending = i < sg.y && cur.rcp_bwd > 0.0f;
+                        const uint32_t fb = code_bwd(cur.code);
+                        T val[COUT];
+                        if (pending) {
+                            const T *dyr = dy_cloud + (size_t)cur.cand * COUT;
+#pragma unroll
+                            for (int c = 0; c < COUT; ++c) val[c] = dyr[c] * (T)cur.rcp_bwd;
+                        }
+                        while (__any(pending)) {
+                            bool blocked = false;
+#pragma unroll
+                            for (int v = 0; v < 3; ++v) {
+                                const int src = (lane & 15) + 16 * v;
+                                const uint32_t ofb = __shfl(pending ? fb : kNoTap, src);
+                                blocked |= (v < sub) && (ofb == fb);
+                            }
+                            if (pending && !blocked) {
+                                T *grow = G + ((size_t)fb * COUT) * kCntStride + cq;
+#pragma unroll
+                                for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += val[c];
+                                pending = false;
+                            }
                         }
                         cur = nxt;
                     }
@@ -850,6 +892,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
 #pragma unroll
             for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
         }
+        __syncthreads();   // red aliases wt / xt: every wave is done reading them
 #pragma unroll
         for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
         __syncthreads();
