@@ -125,10 +125,15 @@ __device__ __forceinline__ void make_query(Query<T> &q, const PointRec<T> &me, c
         q.ulo[a] = wave_min(valid ? q.lo[a] : Limits<T>::inf());
         q.uhi[a] = wave_max(valid ? q.hi[a] : -Limits<T>::inf());
         q.add[a] = (float)((double)st.shift[a] - (double)q.lo[a] * (double)st.inv[a]);
-        // slack: fp32 rounding of v*inv + add at the magnitude of the coordinates involved
-        const float mag = fmaxf(fabsf((float)q.ulo[a]), fabsf((float)q.uhi[a])) * st.inv[a];
-        q.thr[a] = st.halfw[a] + 1.0e-5f + 1.0e-6f * mag;
     }
+    // slack: fp32 rounding of v*inv + add at the magnitude of the coordinates involved (worst axis, so
+    // that an isotropic stencil keeps one common half-width)
+    float mag = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        mag = fmaxf(mag, fmaxf(fabsf((float)q.ulo[a]), fabsf((float)q.uhi[a])) * st.inv[a]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q.thr[a] = st.halfw[a] + 1.0e-5f + 1.0e-6f * mag;
 }
 
 // tap lookup: tapmap[a*maxfull + t] = t/step[a] if t % step[a] == 0 else -1   (.cpp:285-288)
@@ -184,9 +189,11 @@ __device__ __forceinline__ void stage_tile(float *soa, const PointRec<T> &cand)
 
 // Pre-filter of the 64 staged candidates against the lane's query.  Candidate c ends up in bit
 // (31 - c) of m0 for c < 32 and bit (63 - c) of m1 otherwise.
-template <typename T>
-__device__ __forceinline__ void scan_tile(const float *soa, const Query<T> &q, const Stencil<T> &st,
-                                          uint32_t &m0, uint32_t &m1)
+// ISO: all three axes share one acceptance half-width (isotropic stride, every layer of the
+// reference's models) -> one v_max3 with |.| modifiers instead of three subtractions + max3.
+template <typename T, bool ISO>
+__device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> &q, const Stencil<T> &st,
+                                               uint32_t &m0, uint32_t &m1)
 {
     m0 = 0;
     m1 = 0;
@@ -205,14 +212,32 @@ __device__ __forceinline__ void scan_tile(const float *soa, const Query<T> &q, c
             const float dx = zx - __builtin_amdgcn_fmed3f(__builtin_rintf(zx), 0.0f, st.mmax[0]);
             const float dy = zy - __builtin_amdgcn_fmed3f(__builtin_rintf(zy), 0.0f, st.mmax[1]);
             const float dz = zz - __builtin_amdgcn_fmed3f(__builtin_rintf(zz), 0.0f, st.mmax[2]);
-            const float e = fmaxf(fmaxf(fabsf(dx) - q.thr[0], fabsf(dy) - q.thr[1]), fabsf(dz) - q.thr[2]);
-            const uint32_t bit = e <= 0.0f ? 1u : 0u;
+            float e, lim;
+            if (ISO) {
+                e = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                lim = q.thr[0];
+            } else {
+                e = fmaxf(fmaxf(fabsf(dx) - q.thr[0], fabsf(dy) - q.thr[1]), fabsf(dz) - q.thr[2]);
+                lim = 0.0f;
+            }
+            // m = 2*m + (e <= lim): compare into VCC, then one add-with-carry (hipcc would emit
+            // v_cndmask + shift + or for the same thing)
             if (c4 < 8)
-                m0 = (m0 << 1) | bit;
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m0) : "v"(e), "v"(lim) : "vcc");
             else
-                m1 = (m1 << 1) | bit;
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m1) : "v"(e), "v"(lim) : "vcc");
         }
     }
+}
+template <typename T>
+__device__ __forceinline__ void scan_tile(const float *soa, const Query<T> &q, const Stencil<T> &st,
+                                          uint32_t &m0, uint32_t &m1)
+{
+    // wave-uniform choice (kernel argument + wave-uniform slack)
+    if (q.thr[0] == q.thr[1] && q.thr[1] == q.thr[2])
+        scan_tile_impl<T, true>(soa, q, st, m0, m1);
+    else
+        scan_tile_impl<T, false>(soa, q, st, m0, m1);
 }
 
 // Candidate tiles whose bounding box meets the union of the wave's filter boxes: 64 tiles per

@@ -514,16 +514,14 @@ __global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__rest
         if (sg.y == kSegOverflow) continue;
         PairEntry *pe = pairs + sg.x;
         for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
-            const uint32_t code = pe[e].code, fwd = code_fwd(code), bwd = code_bwd(code);
+            PairEntry en = pe[e];                                                    // one 16-byte load
+            const uint32_t fwd = code_fwd(en.code), bwd = code_bwd(en.code);
             if (fwd == kNoTap) continue;
-            const int cf = cnt_cloud[(size_t)qorig[code_q(code)] * ntap + fwd];
-            float rb = 0.0f;
-            if (bwd != kNoTap) {
-                const int cb = cnt_cloud[(size_t)pe[e].cand * ntap + bwd];
-                if (cb != 0) rb = 1.0f / (float)cb;                                  // .cpp:678-679
-            }
-            pe[e].rcp_fwd = 1.0f / (float)cf;
-            pe[e].rcp_bwd = rb;
+            const int cf = cnt_cloud[(size_t)qorig[code_q(en.code)] * ntap + fwd];
+            const int cb = bwd != kNoTap ? cnt_cloud[(size_t)en.cand * ntap + bwd] : 0;
+            en.rcp_fwd = 1.0f / (float)cf;
+            en.rcp_bwd = cb != 0 ? 1.0f / (float)cb : 0.0f;                          // .cpp:678-679
+            pe[e] = en;                                                              // one 16-byte store
         }
     }
 }
