@@ -1,0 +1,157 @@
+// tf_conv3p_shim.cc -- TensorFlow custom-op shim over the C ABI of include/conv3p.h.
+//
+// NOT BUILT IN THIS REPOSITORY: TensorFlow (headers + libtensorflow_framework) is not part of the
+// image, so this file has never been compiled here; it is the binding a maintainer of
+// hkust-vgd/pointwise adds to get a drop-in tf_conv3p.so (see INTEGRATION.md for the build line).
+//
+// It keeps the reference's operator surface exactly:
+//   REGISTER_OP("Conv3p") / REGISTER_OP("Conv3pGrad")  -- same op names, attr T:{float,double},
+//   same input names, order and dtypes, same outputs   (tf_ops/conv3p/register_op.cpp:44-75),
+// so pointcnn2_acsd.py:10-31 and scene_seg/pointcnn_scene_seg_acsd.py:9-30 load it unchanged
+// (tf.load_op_library + conv3p_module.conv3p / conv3p_grad + the Python-side RegisterGradient).
+//
+// Differences from the reference's registration, all supersets:
+//   * `stride` and `voxel_size` are declared HostMemory on the GPU kernel, so their values are
+//     read without the blocking cudaMemcpy D2H of tf_conv3p_atrous.cu:577,586;
+//   * a shape function is attached (the reference registers none);
+//   * scratch comes from one allocate_temp per Compute (conv3p_workspace_bytes).
+#include "tensorflow/core/framework/op.h"
+#include "tensorflow/core/framework/op_kernel.h"
+#include "tensorflow/core/framework/register_types.h"
+#include "tensorflow/core/framework/shape_inference.h"
+
+#include "conv3p.h"   // -I <repo>/include
+
+using namespace tensorflow;
+
+REGISTER_OP("Conv3p")
+    .Attr("T: {float, double}")
+    .Input("points: T")
+    .Input("input: T")
+    .Input("filter: T")
+    .Input("stride: int32")
+    .Input("voxel_size: T")
+    .Output("output: T")
+    .SetShapeFn([](shape_inference::InferenceContext *c) {
+        shape_inference::ShapeHandle pts, flt;
+        TF_RETURN_IF_ERROR(c->WithRank(c->input(0), 3, &pts));
+        TF_RETURN_IF_ERROR(c->WithRank(c->input(2), 5, &flt));
+        c->set_output(0, c->MakeShape({c->Dim(pts, 0), c->Dim(pts, 1), c->Dim(flt, 4)}));
+        return Status::OK();
+    });
+
+REGISTER_OP("Conv3pGrad")
+    .Attr("T: {float, double}")
+    .Input("grad_from_next: T")
+    .Input("points: T")
+    .Input("input: T")
+    .Input("filter: T")
+    .Input("stride: int32")
+    .Input("voxel_size: T")
+    .Output("grad_input: T")
+    .Output("grad_filter: T")
+    .SetShapeFn([](shape_inference::InferenceContext *c) {
+        c->set_output(0, c->input(2));
+        c->set_output(1, c->input(3));
+        return Status::OK();
+    });
+
+namespace {
+
+template <typename T> struct Abi;
+template <> struct Abi<float> {
+    static constexpr int kElem = 4;
+    static constexpr auto forward = conv3p_forward_f32;
+    static constexpr auto backward = conv3p_backward_f32;
+};
+template <> struct Abi<double> {
+    static constexpr int kElem = 8;
+    static constexpr auto forward = conv3p_forward_f64;
+    static constexpr auto backward = conv3p_backward_f64;
+};
+
+Status FromCode(int rc, const char *what)
+{
+    if (rc == CONV3P_OK) return Status::OK();
+    if (rc == CONV3P_ERR_INVALID_ARGUMENT) return errors::InvalidArgument(what, ": ", conv3p_status_string(rc));
+    return errors::Internal(what, ": ", conv3p_status_string(rc));
+}
+
+void *StreamOf(OpKernelContext *ctx)
+{
+    // ROCm build of TensorFlow: the StreamExecutor stream wraps a hipStream_t
+    return *reinterpret_cast<void **>(ctx->op_device_context()->stream()->implementation()->GpuStreamMemberHack());
+}
+
+template <typename T> class Conv3pHipOp : public OpKernel {
+ public:
+    explicit Conv3pHipOp(OpKernelConstruction *c) : OpKernel(c) {}
+    void Compute(OpKernelContext *ctx) override
+    {
+        const Tensor &points = ctx->input(0), &input = ctx->input(1), &filter = ctx->input(2);
+        const Tensor &stride = ctx->input(3), &voxel = ctx->input(4);
+        // the reference's checks and messages (tf_conv3p_atrous.cpp:410-443)
+        OP_REQUIRES(ctx, points.dims() == 3, errors::InvalidArgument("Conv3p expects (batch_size, num_points, 3) points shape"));
+        OP_REQUIRES(ctx, input.dim_size(0) == points.dim_size(0), errors::InvalidArgument("Conv3p expects points and input tensor to have the same batch size"));
+        OP_REQUIRES(ctx, input.dim_size(1) == points.dim_size(1), errors::InvalidArgument("Conv3p expects points and input tensor to have the same number of points"));
+        OP_REQUIRES(ctx, filter.dim_size(3) == input.dim_size(2), errors::InvalidArgument("Conv3p expects filter channels to be matched with input channels"));
+        OP_REQUIRES(ctx, stride.dim_size(0) == 3, errors::InvalidArgument("Conv3p expects stride tensor to have size 3."));
+        OP_REQUIRES(ctx, voxel.dim_size(0) == 1, errors::InvalidArgument("Conv3p expects voxel tensor to have dimension 1."));
+        const int B = points.dim_size(0), N = points.dim_size(1), Cin = input.dim_size(2), Cout = filter.dim_size(4);
+        const int fz = filter.dim_size(0), fy = filter.dim_size(1), fx = filter.dim_size(2);
+        Tensor *out = nullptr;
+        OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({B, N, Cout}), &out));
+        const size_t need = conv3p_workspace_bytes(CONV3P_PASS_FORWARD, Abi<T>::kElem, B, N, Cin, Cout, fz, fy, fx);
+        Tensor ws;
+        OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT8, TensorShape({(int64)need + 256}), &ws));
+        char *wp = reinterpret_cast<char *>(ws.flat<int8>().data());
+        wp += (256 - reinterpret_cast<uintptr_t>(wp) % 256) % 256;
+        const int rc = Abi<T>::forward(points.flat<T>().data(), input.flat<T>().data(), filter.flat<T>().data(),
+                                       stride.flat<int32>().data() /* host memory */, voxel.flat<T>()(0), B, N, Cin,
+                                       Cout, fz, fy, fx, out->flat<T>().data(), wp, need, StreamOf(ctx));
+        OP_REQUIRES_OK(ctx, FromCode(rc, "Conv3p"));
+    }
+};
+
+template <typename T> class Conv3pGradHipOp : public OpKernel {
+ public:
+    explicit Conv3pGradHipOp(OpKernelConstruction *c) : OpKernel(c) {}
+    void Compute(OpKernelContext *ctx) override
+    {
+        const Tensor &grad = ctx->input(0), &points = ctx->input(1), &input = ctx->input(2), &filter = ctx->input(3);
+        const Tensor &stride = ctx->input(4), &voxel = ctx->input(5);
+        OP_REQUIRES(ctx, stride.dim_size(0) == 3, errors::InvalidArgument("Conv3p expects stride tensor to have size 3."));
+        OP_REQUIRES(ctx, voxel.dim_size(0) == 1, errors::InvalidArgument("Conv3p expects voxel tensor to have dimension 1."));
+        const int B = points.dim_size(0), N = points.dim_size(1), Cin = filter.dim_size(3), Cout = filter.dim_size(4);
+        const int fz = filter.dim_size(0), fy = filter.dim_size(1), fx = filter.dim_size(2);
+        // tf_conv3p_atrous.cpp:583-585
+        OP_REQUIRES(ctx, grad.dim_size(0) == B, errors::InvalidArgument("backprop grad tensor has wrong size for dim 0"));
+        OP_REQUIRES(ctx, grad.dim_size(1) == N, errors::InvalidArgument("backprop grad tensor has wrong size for dim 1"));
+        OP_REQUIRES(ctx, grad.dim_size(2) == Cout, errors::InvalidArgument("backprop grad tensor has wrong size for dim 2"));
+        Tensor *dx = nullptr, *dw = nullptr;
+        OP_REQUIRES_OK(ctx, ctx->allocate_output(0, input.shape(), &dx));
+        OP_REQUIRES_OK(ctx, ctx->allocate_output(1, filter.shape(), &dw));
+        const size_t need = conv3p_workspace_bytes(CONV3P_PASS_BACKWARD, Abi<T>::kElem, B, N, Cin, Cout, fz, fy, fx);
+        Tensor ws;
+        OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT8, TensorShape({(int64)need + 256}), &ws));
+        char *wp = reinterpret_cast<char *>(ws.flat<int8>().data());
+        wp += (256 - reinterpret_cast<uintptr_t>(wp) % 256) % 256;
+        const int rc = Abi<T>::backward(grad.flat<T>().data(), points.flat<T>().data(), input.flat<T>().data(),
+                                        filter.flat<T>().data(), stride.flat<int32>().data(), voxel.flat<T>()(0), B, N,
+                                        Cin, Cout, fz, fy, fx, dx->flat<T>().data(), dw->flat<T>().data(), wp, need,
+                                        StreamOf(ctx));
+        OP_REQUIRES_OK(ctx, FromCode(rc, "Conv3pGrad"));
+    }
+};
+
+}  // namespace
+
+#define REGISTER_HIP(T)                                                                                   \
+    REGISTER_KERNEL_BUILDER(Name("Conv3p").Device(DEVICE_GPU).TypeConstraint<T>("T")                     \
+                                .HostMemory("stride").HostMemory("voxel_size"), Conv3pHipOp<T>);          \
+    REGISTER_KERNEL_BUILDER(Name("Conv3pGrad").Device(DEVICE_GPU).TypeConstraint<T>("T")                 \
+                                .HostMemory("stride").HostMemory("voxel_size"), Conv3pGradHipOp<T>);
+REGISTER_HIP(float)
+REGISTER_HIP(double)
+// The DEVICE_CPU kernels of the drop-in library are the reference's own tf_conv3p_atrous.cpp object,
+// linked unchanged (tf_conv3p_compile.sh:32): this repository ships no CPU implementation of the op.
