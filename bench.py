@@ -44,8 +44,10 @@ def algorithmic_bytes(kind, B, N, cin, cout):
         return pts * (12 + 4 * cin + 4 * cout)
     if kind == "backward_kernel":
         return pts * (12 + 4 * cin + 4 * cout + 4 * cin)
-    if kind == "count_kernel":
-        return pts * (12 + 4 * 27)
+    if kind == "search_kernel":
+        # not one of the op's tensors-in/tensors-out kernels: its own compulsory traffic is the staged point
+        # record in (16 B) and the per-tap populations out (4*27 B); pair lists are an implementation choice
+        return pts * (16 + 4 * 27)
     return 0
 
 
@@ -161,6 +163,8 @@ def main():
         roofline = None
         if dom is not None:
             n, ms = kinds[dom]
+            # one real launch per layer and step does the work (the cache turns the repeats into early exits,
+            # which stay in the duration sum): achieved = sum(bytes) / sum(time) over ALL launches of the kernel
             per_step_bytes = sum(algorithmic_bytes(dom, B_PER_GPU, N_POINTS, ci, co) for ci, co, _ in st.layers)
             launches_per_step = n / args.steps
             bytes_per_launch = per_step_bytes / max(launches_per_step, 1)
@@ -170,7 +174,10 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom)
+                    t = json.load(open(tpath)).get(dom)
+                    # measured in separate rocprofv3 --pmc passes (tools/collect_profiles.sh): HBM bytes per launch,
+                    # FETCH_SIZE raw + WRITE_SIZE (lower bound; see tools/traffic_json.py for the gfx950 caveat)
+                    traffic = t["hbm_bytes_lower"] if isinstance(t, dict) else t
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

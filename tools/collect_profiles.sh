@@ -1,0 +1,28 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): produces the evidence files that get committed under profiles/.
+#   tools/collect_profiles.sh <tag>      e.g. r01
+# 1. bench.py (full, with CPU baseline)                      -> gpurun_out/<tag>_bench.json
+# 2. rocprofv3 --kernel-trace --stats of the same command    -> gpurun_out/<tag>_kernel_stats.txt
+# 3. PMC passes, each in its own run (FETCH_SIZE / WRITE_SIZE cannot share a pass; no trace domains
+#    besides --kernel-trace)                                  -> gpurun_out/<tag>_pmc_*.txt, traffic json
+set -u
+TAG=${1:-r01}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+STEPS=20; WARM=5
+
+python $ROOT/bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o t -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu > $OUT/${TAG}_trace.log 2>&1
+python $ROOT/tools/pmc_query.py $OUT/${TAG}_trace/t_results.db > $OUT/${TAG}_kernel_stats.txt 2>&1
+
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
+  N=$(echo $C | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$N -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu > $OUT/${TAG}_pmc_$N.log 2>&1
+  python $ROOT/tools/pmc_query.py $OUT/${TAG}_pmc_$N/p_results.db conv3p > $OUT/${TAG}_pmc_$N.txt 2>&1
+done
+python $ROOT/tools/traffic_json.py $OUT/${TAG}_pmc_FETCH_SIZE/p_results.db $OUT/${TAG}_pmc_WRITE_SIZE/p_results.db > $OUT/${TAG}_traffic.json
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_*/   # keep the text summaries, drop the databases
+tail -c 1500 $OUT/${TAG}_bench.json; echo; head -14 $OUT/${TAG}_kernel_stats.txt; cat $OUT/${TAG}_traffic.json
