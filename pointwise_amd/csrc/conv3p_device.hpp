@@ -133,7 +133,8 @@ __device__ __forceinline__ void make_query(Query<T> &q, const PointRec<T> &me, c
     for (int a = 0; a < 3; ++a)
         mag = fmaxf(mag, fmaxf(fabsf((float)q.ulo[a]), fabsf((float)q.uhi[a])) * st.inv[a]);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) q.thr[a] = st.halfw[a] + 1.0e-5f + 1.0e-6f * mag;
+    for (int a = 0; a < 3; ++a)   // + one ulp: scan_tile tests |d| - thr < 0 (sign bit) for |d| <= thr
+        q.thr[a] = __builtin_nextafterf(st.halfw[a] + 1.0e-5f + 1.0e-6f * mag, 3.0e38f);
 }
 
 // tap lookup: tapmap[a*maxfull + t] = t/step[a] if t % step[a] == 0 else -1   (.cpp:285-288)
@@ -212,20 +213,18 @@ __device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> 
             const float dx = zx - __builtin_amdgcn_fmed3f(__builtin_rintf(zx), 0.0f, st.mmax[0]);
             const float dy = zy - __builtin_amdgcn_fmed3f(__builtin_rintf(zy), 0.0f, st.mmax[1]);
             const float dz = zz - __builtin_amdgcn_fmed3f(__builtin_rintf(zz), 0.0f, st.mmax[2]);
-            float e, lim;
-            if (ISO) {
-                e = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-                lim = q.thr[0];
-            } else {
-                e = fmaxf(fmaxf(fabsf(dx) - q.thr[0], fabsf(dy) - q.thr[1]), fabsf(dz) - q.thr[2]);
-                lim = 0.0f;
-            }
-            // m = 2*m + (e <= lim): compare into VCC, then one add-with-carry (hipcc would emit
-            // v_cndmask + shift + or for the same thing)
-            if (c4 < 8)
-                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m0) : "v"(e), "v"(lim) : "vcc");
+            // e < 0  <=>  every axis is within its half-width (thr was bumped by one ulp in make_query so
+            // that "<" here is "<=" there).  The sign bit of e is shifted into the mask with one
+            // v_alignbit_b32: m = (m << 1) | (bits(e) >> 31) -- no VCC / SGPR round trip.
+            float e;
+            if (ISO)
+                e = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) - q.thr[0];
             else
-                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m1) : "v"(e), "v"(lim) : "vcc");
+                e = fmaxf(fmaxf(fabsf(dx) - q.thr[0], fabsf(dy) - q.thr[1]), fabsf(dz) - q.thr[2]);
+            if (c4 < 8)
+                m0 = __builtin_amdgcn_alignbit(m0, __builtin_bit_cast(uint32_t, e), 31);
+            else
+                m1 = __builtin_amdgcn_alignbit(m1, __builtin_bit_cast(uint32_t, e), 31);
         }
     }
 }

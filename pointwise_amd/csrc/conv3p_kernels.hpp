@@ -354,22 +354,26 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
         // ---- P1: pre-filter
         uint32_t mine = 0;   // this wave's pre-filter hits of centre `lane`
         for (int base = ct0; base < ct1; base += 64) {
-            uint64_t live = overlapping_tiles(cloud_box, ct1, base, q);
-            for (int i = wave; i < 64 && base + i < ct1; i += kWavesPerBlock) {
-                const int ct = base + i;
-                uint32_t any = 0;
-                if ((live >> i) & 1ull) {
-                    stage_tile(soa, cloud_pts[(size_t)ct * kTile + lane]);
-                    __builtin_amdgcn_wave_barrier();
-                    uint32_t m0, m1;
-                    scan_tile(soa, q, st, m0, m1);
-                    __builtin_amdgcn_wave_barrier();
-                    if (!qvalid) m0 = m1 = 0;
-                    masks[(size_t)(ct - ct0) * 64 + lane] = ((uint64_t)m1 << 32) | m0;
-                    mine += __popc(m0) + __popc(m1);
-                    any = __any((m0 | m1) != 0) ? 1u : 0u;
-                }
-                if (lane == 0) tot[ct - ct0] = any;
+            const uint64_t live = overlapping_tiles(cloud_box, ct1, base, q);
+            // this wave's share: candidate tiles i == wave (mod 4) of the group
+            for (int i = wave + lane * kWavesPerBlock; i < 64 && base + i < ct1; i += 64 * kWavesPerBlock)
+                tot[base + i - ct0] = 0;
+            uint64_t todo = live & (0x1111111111111111ull << wave);
+            PointRec<T> rec;
+            if (todo) rec = cloud_pts[(size_t)(base + __builtin_ctzll(todo)) * kTile + lane];
+            while (todo) {
+                const int ct = base + __builtin_ctzll(todo);
+                todo &= todo - 1;
+                stage_tile(soa, rec);
+                if (todo) rec = cloud_pts[(size_t)(base + __builtin_ctzll(todo)) * kTile + lane];   // prefetch
+                __builtin_amdgcn_wave_barrier();
+                uint32_t m0, m1;
+                if (CONV3P_ABLATE & 32) { m0 = m1 = 0; } else scan_tile(soa, q, st, m0, m1);
+                __builtin_amdgcn_wave_barrier();
+                if (!qvalid) m0 = m1 = 0;
+                masks[(size_t)(ct - ct0) * 64 + lane] = ((uint64_t)m1 << 32) | m0;
+                mine += __popc(m0) + __popc(m1);
+                if (__any((m0 | m1) != 0) && lane == 0) tot[ct - ct0] = 1;
             }
         }
         nqw[wave * 64 + lane] = mine;
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
             int have = 0;
             auto drain = [&](int n) {
                 // lanes 0..n-1 each resolve one (centre, candidate) pair
-                if (lane < n) {
+                if (!(CONV3P_ABLATE & 64) && lane < n) {
                     const uint32_t e = stream[lane];
                     const uint32_t ql = (e >> 6) & 63u, c = e & 63u, ct = e >> 12;
                     const CentreRec<T> cr = centres[ql];
