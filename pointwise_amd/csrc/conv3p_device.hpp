@@ -92,6 +92,53 @@ template <typename T> __device__ __forceinline__ T wave_max(T v)
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+
+// Gather of a feature row with dword alignment only: rows are C*sizeof(T) bytes apart, so the compiler
+// cannot prove 16-B alignment and would emit C scalar loads, each of which costs the texture-addresser a
+// full pass over 64 scattered cache lines.  global_load_dwordx4 only needs dword alignment on gfx950:
+// load 4 elements at a time through an under-aligned vector type.
+template <typename T, int C> struct RowLoader {
+    static __device__ __forceinline__ void load(const T *__restrict__ p, T (&out)[C])
+    {
+#pragma unroll
+        for (int i = 0; i < C; ++i) out[i] = p[i];
+    }
+};
+typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+template <int C> struct RowLoader<float, C> {
+    static __device__ __forceinline__ void load(const float *__restrict__ p, float (&out)[C])
+    {
+        int i = 0;
+#pragma unroll
+        for (; i + 4 <= C; i += 4) {
+            const float4_a4 v = *reinterpret_cast<const float4_a4 *>(p + i);
+            out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+        }
+        if (i + 2 <= C) {
+            const float2_a4 v = *reinterpret_cast<const float2_a4 *>(p + i);
+            out[i] = v.x; out[i + 1] = v.y;
+            i += 2;
+        }
+        if (i < C) out[i] = p[i];
+    }
+};
+
+
+// Value of lane (l ^ 16) / (l ^ 32) without touching LDS: gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange 16- / 32-lane blocks between two registers (VALU, no ds_bpermute round trip).
+__device__ __forceinline__ uint32_t lane_xor16(uint32_t x)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    // r[0]: odd 16-lane rows hold x of the row below; r[1]: even rows hold x of the row above
+    return ((threadIdx.x >> 4) & 1) ? r[0] : r[1];
+}
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}
+
 template <typename T> struct Limits;
 template <> struct Limits<float> {
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
@@ -133,8 +180,7 @@ __device__ __forceinline__ void make_query(Query<T> &q, const PointRec<T> &me, c
     for (int a = 0; a < 3; ++a)
         mag = fmaxf(mag, fmaxf(fabsf((float)q.ulo[a]), fabsf((float)q.uhi[a])) * st.inv[a]);
 #pragma unroll
-    for (int a = 0; a < 3; ++a)   // + one ulp: scan_tile tests |d| - thr < 0 (sign bit) for |d| <= thr
-        q.thr[a] = __builtin_nextafterf(st.halfw[a] + 1.0e-5f + 1.0e-6f * mag, 3.0e38f);
+    for (int a = 0; a < 3; ++a) q.thr[a] = st.halfw[a] + 1.0e-5f + 1.0e-6f * mag;
 }
 
 // tap lookup: tapmap[a*maxfull + t] = t/step[a] if t % step[a] == 0 else -1   (.cpp:285-288)
@@ -213,18 +259,20 @@ __device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> 
             const float dx = zx - __builtin_amdgcn_fmed3f(__builtin_rintf(zx), 0.0f, st.mmax[0]);
             const float dy = zy - __builtin_amdgcn_fmed3f(__builtin_rintf(zy), 0.0f, st.mmax[1]);
             const float dz = zz - __builtin_amdgcn_fmed3f(__builtin_rintf(zz), 0.0f, st.mmax[2]);
-            // e < 0  <=>  every axis is within its half-width (thr was bumped by one ulp in make_query so
-            // that "<" here is "<=" there).  The sign bit of e is shifted into the mask with one
-            // v_alignbit_b32: m = (m << 1) | (bits(e) >> 31) -- no VCC / SGPR round trip.
-            float e;
-            if (ISO)
-                e = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) - q.thr[0];
-            else
+            float e, lim;
+            if (ISO) {
+                e = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                lim = q.thr[0];
+            } else {
                 e = fmaxf(fmaxf(fabsf(dx) - q.thr[0], fabsf(dy) - q.thr[1]), fabsf(dz) - q.thr[2]);
+                lim = 0.0f;
+            }
+            // m = 2*m + (e <= lim): compare into VCC, then one add-with-carry.  (Measured alternatives:
+            // hipcc's v_cndmask + shift + or: 7 % slower; sign bit via v_alignbit_b32: 10 % slower.)
             if (c4 < 8)
-                m0 = __builtin_amdgcn_alignbit(m0, __builtin_bit_cast(uint32_t, e), 31);
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m0) : "v"(e), "v"(lim) : "vcc");
             else
-                m1 = __builtin_amdgcn_alignbit(m1, __builtin_bit_cast(uint32_t, e), 31);
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m1) : "v"(e), "v"(lim) : "vcc");
         }
     }
 }

@@ -596,8 +596,9 @@ __global__ __launch_bounds__(256) void forward_kernel(
         const T *xr = in_cloud + (size_t)cand * cin;
         if constexpr (kSmall) {
             T xs[CIN];
+            RowLoader<T, CIN>::load(xr, xs);
 #pragma unroll
-            for (int k = 0; k < CIN; ++k) xs[k] = xr[k] * rcp;           // x / count, .cpp:492
+            for (int k = 0; k < CIN; ++k) xs[k] *= rcp;                  // x / count, .cpp:492
             const T *wf = w_lds + (size_t)f * CIN * COUT;
 #pragma unroll
             for (int k = 0; k < CIN; ++k)
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(256) void forward_kernel(
                 // read 4 consecutive pair records per step (64 contiguous bytes)
                 const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                 const PairEntry *pe = pairs + sg.x;
-                PairEntry cur = pe[sub < sg.y ? sub : 0];
+                PairEntry cur = pe[(uint32_t)sub < sg.y ? sub : 0];
                 for (uint32_t i = sub; __any(i < sg.y); i += 4) {
                     const uint32_t nx = i + 4;
                     const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
@@ -809,7 +810,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     // lower sub-lane goes first (fixed order), the other retries -> race-free, reproducible.
                     const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                     const PairEntry *pe = pairs + sg.x;
-                    PairEntry cur = pe[sub < sg.y ? sub : 0];
+                    PairEntry cur = pe[(uint32_t)sub < sg.y ? sub : 0];
+                    T ablate_sink = (T)0;
                     for (uint32_t i = sub; __any(i < sg.y); i += 4) {
                         const uint32_t nx = i + 4;
                         const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
@@ -818,27 +820,64 @@ __global__ __launch_bounds__(256) void backward_kernel(
                         const uint32_t fb = code_bwd(cur.code);
                         T val[COUT];
                         if (pending) {
-                            const T *dyr = dy_cloud + (size_t)cur.cand * COUT;
+                            if (CONV3P_ABLATE & 128) {
 #pragma unroll
-                            for (int c = 0; c < COUT; ++c) val[c] = dyr[c] * (T)cur.rcp_bwd;
-                        }
-                        while (__any(pending)) {
-                            bool blocked = false;
+                                for (int c = 0; c < COUT; ++c) val[c] = (T)cur.rcp_bwd;
+                            } else {
+                                RowLoader<T, COUT>::load(dy_cloud + (size_t)cur.cand * COUT, val);
 #pragma unroll
-                            for (int v = 0; v < 3; ++v) {
-                                const int src = (lane & 15) + 16 * v;
-                                const uint32_t ofb = __shfl(pending ? fb : kNoTap, src);
-                                blocked |= (v < sub) && (ofb == fb);
+                                for (int c = 0; c < COUT; ++c) val[c] *= (T)cur.rcp_bwd;
                             }
-                            if (pending && !blocked) {
+                        }
+                        if (CONV3P_ABLATE & 256) {
+                            if (pending) {
+#pragma unroll
+                                for (int c = 0; c < COUT; ++c) ablate_sink += val[c];
+                            }
+                            pending = false;
+                        }
+                        if (CONV3P_ABLATE & 512) {
+                            if (pending) {
                                 T *grow = G + ((size_t)fb * COUT) * kCntStride + cq;
 #pragma unroll
-                                for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += val[c];
-                                pending = false;
+                                for (int c = 0; c < COUT; ++c)
+                                    __hip_atomic_fetch_add(&grow[c * kCntStride], val[c], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
+                            pending = false;
+                        }
+                        // Sub-lanes of one centre that target the same tap are merged first (fixed order:
+                        // partner distance 16, 32, 48 lanes; the lower sub-lane absorbs the higher one), so a
+                        // single race-free read-modify-write round follows.  Neighbouring candidates usually
+                        // share a tap, so without the merge this would take 2-3 rounds.
+#pragma unroll
+                        for (int step = 0; step < 3; ++step) {
+                            const uint32_t mine_fb = pending ? fb : kNoTap;
+                            uint32_t pfb;
+                            bool lower;
+                            if (step == 0) { pfb = lane_xor16(mine_fb); lower = (sub & 1) == 0; }
+                            else if (step == 1) { pfb = lane_xor32(mine_fb); lower = sub < 2; }
+                            else { pfb = lane_xor32(lane_xor16(mine_fb)); lower = sub < 2; }
+                            const bool same = pending && pfb == fb;
+                            if (__any(same)) {
+#pragma unroll
+                                for (int c = 0; c < COUT; ++c) {
+                                    const uint32_t bits = __builtin_bit_cast(uint32_t, (float)val[c]);
+                                    const uint32_t pb = step == 0 ? lane_xor16(bits)
+                                                      : step == 1 ? lane_xor32(bits) : lane_xor32(lane_xor16(bits));
+                                    if (same && lower) val[c] += (T)__builtin_bit_cast(float, pb);
+                                }
+                                if (same && !lower) pending = false;
+                            }
+                        }
+                        if (pending) {
+                            T *grow = G + ((size_t)fb * COUT) * kCntStride + cq;
+#pragma unroll
+                            for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += val[c];
                         }
                         cur = nxt;
                     }
+                    if (CONV3P_ABLATE & 256) G[cq] += ablate_sink;
                 } else {
                     const uint2 sg = segs[tile_id * ngroups + g];
                     const PairEntry *pe = pairs + sg.x;
