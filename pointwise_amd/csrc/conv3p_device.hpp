@@ -223,22 +223,31 @@ __device__ __forceinline__ int exact_tap(const PointRec<T> &v, const Query<T> &q
     return (tz * st.ext[1] + ty) * st.ext[0] + tx;           // .cpp:290
 }
 
-// Stage one candidate tile for the pre-filter: lane l writes its point's fp32 coordinates to the
-// wave's SoA slot (soa[0..63] = x, [64..127] = y, [128..191] = z).
+// Stage one candidate tile for the pre-filter: lane l writes its point's fp32 coordinates, already
+// multiplied by inv = 1/(step*voxel), to the wave's SoA slot (soa[0..63] = x, [64..127] = y,
+// [128..191] = z), so that the per-pair arithmetic starts with a v_add instead of a v_fma.
 template <typename T>
-__device__ __forceinline__ void stage_tile(float *soa, const PointRec<T> &cand)
+__device__ __forceinline__ void stage_tile(float *soa, const PointRec<T> &cand, const Stencil<T> &st)
 {
     const int lane = threadIdx.x & 63;
-    soa[lane] = (float)cand.x;
-    soa[64 + lane] = (float)cand.y;
-    soa[128 + lane] = (float)cand.z;
+    soa[lane] = (float)cand.x * st.inv[0];
+    soa[64 + lane] = (float)cand.y * st.inv[1];
+    soa[128 + lane] = (float)cand.z * st.inv[2];
 }
 
 // Pre-filter of the 64 staged candidates against the lane's query.  Candidate c ends up in bit
 // (31 - c) of m0 for c < 32 and bit (63 - c) of m1 otherwise.
-// ISO: all three axes share one acceptance half-width (isotropic stride, every layer of the
-// reference's models) -> one v_max3 with |.| modifiers instead of three subtractions + max3.
-template <typename T, bool ISO>
+// Instruction choice follows the measured issue rates on gfx950 (tools/ubench/valu_rate.hip): plain
+// VOP2 ops (v_add/v_sub) issue in ~2.7 cycles per wave, every VOP3/VOP1 op (v_fma, v_rndne, v_med3,
+// v_max3, v_min3, v_cmp) in ~4.2.  z = v*inv + add is a v_add on pre-scaled coordinates.
+//   TAPS3 (filters with 3 taps per axis, every layer of the reference's models):
+//       |d| = min3(|z|, |z-1|, |z-2|)                 2 v_sub + 1 v_min3   (9.6 cycles/axis)
+//   otherwise  d = z - med3(rndne(z), 0, ext-1)       v_rndne + v_med3 + v_sub (11 cycles/axis)
+//   ISO (one half-width for all axes): hit = max3(|dx|,|dy|,|dz|) <= thr     1 v_max3
+// and the mask bit is inserted with v_cmp + v_addc (hipcc's cndmask+shift+or: 7 % slower; sign bit via
+// v_alignbit_b32: 10 % slower; an all-integer packed-phase filter was 1.5x cheaper per pair but its
+// coarser acceptance lengthened the pair lists enough to cancel the gain).
+template <typename T, bool ISO, bool TAPS3>
 __device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> &q, const Stencil<T> &st,
                                                uint32_t &m0, uint32_t &m1)
 {
@@ -253,22 +262,25 @@ __device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> 
         const float vx[4] = {X.x, X.y, X.z, X.w}, vy[4] = {Y.x, Y.y, Y.z, Y.w}, vz[4] = {Z.x, Z.y, Z.z, Z.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float zx = __builtin_fmaf(vx[u], st.inv[0], q.add[0]);
-            const float zy = __builtin_fmaf(vy[u], st.inv[1], q.add[1]);
-            const float zz = __builtin_fmaf(vz[u], st.inv[2], q.add[2]);
-            const float dx = zx - __builtin_amdgcn_fmed3f(__builtin_rintf(zx), 0.0f, st.mmax[0]);
-            const float dy = zy - __builtin_amdgcn_fmed3f(__builtin_rintf(zy), 0.0f, st.mmax[1]);
-            const float dz = zz - __builtin_amdgcn_fmed3f(__builtin_rintf(zz), 0.0f, st.mmax[2]);
+            const float zx = vx[u] + q.add[0], zy = vy[u] + q.add[1], zz = vz[u] + q.add[2];
+            float ax, ay, az;   // distance to the nearest accepted lattice point
+            if (TAPS3) {
+                ax = fminf(fminf(fabsf(zx), fabsf(zx - 1.0f)), fabsf(zx - 2.0f));
+                ay = fminf(fminf(fabsf(zy), fabsf(zy - 1.0f)), fabsf(zy - 2.0f));
+                az = fminf(fminf(fabsf(zz), fabsf(zz - 1.0f)), fabsf(zz - 2.0f));
+            } else {
+                ax = fabsf(zx - __builtin_amdgcn_fmed3f(__builtin_rintf(zx), 0.0f, st.mmax[0]));
+                ay = fabsf(zy - __builtin_amdgcn_fmed3f(__builtin_rintf(zy), 0.0f, st.mmax[1]));
+                az = fabsf(zz - __builtin_amdgcn_fmed3f(__builtin_rintf(zz), 0.0f, st.mmax[2]));
+            }
             float e, lim;
             if (ISO) {
-                e = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+                e = fmaxf(fmaxf(ax, ay), az);
                 lim = q.thr[0];
             } else {
-                e = fmaxf(fmaxf(fabsf(dx) - q.thr[0], fabsf(dy) - q.thr[1]), fabsf(dz) - q.thr[2]);
+                e = fmaxf(fmaxf(ax - q.thr[0], ay - q.thr[1]), az - q.thr[2]);
                 lim = 0.0f;
             }
-            // m = 2*m + (e <= lim): compare into VCC, then one add-with-carry.  (Measured alternatives:
-            // hipcc's v_cndmask + shift + or: 7 % slower; sign bit via v_alignbit_b32: 10 % slower.)
             if (c4 < 8)
                 asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m0) : "v"(e), "v"(lim) : "vcc");
             else
@@ -280,11 +292,13 @@ template <typename T>
 __device__ __forceinline__ void scan_tile(const float *soa, const Query<T> &q, const Stencil<T> &st,
                                           uint32_t &m0, uint32_t &m1)
 {
-    // wave-uniform choice (kernel argument + wave-uniform slack)
-    if (q.thr[0] == q.thr[1] && q.thr[1] == q.thr[2])
-        scan_tile_impl<T, true>(soa, q, st, m0, m1);
+    // wave-uniform choice (kernel arguments + wave-uniform slack)
+    const bool iso = q.thr[0] == q.thr[1] && q.thr[1] == q.thr[2];
+    const bool taps3 = st.ext[0] == 3 && st.ext[1] == 3 && st.ext[2] == 3;
+    if (iso && taps3)
+        scan_tile_impl<T, true, true>(soa, q, st, m0, m1);
     else
-        scan_tile_impl<T, false>(soa, q, st, m0, m1);
+        scan_tile_impl<T, false, false>(soa, q, st, m0, m1);
 }
 
 // Candidate tiles whose bounding box meets the union of the wave's filter boxes: 64 tiles per
@@ -344,7 +358,7 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
             tiles &= tiles - 1;
             if ((seen++ & (stride - 1)) != first) continue;   // stride is a power of two
             const PointRec<T> *tile = cloud_pts + (size_t)ct * kTile;
-            stage_tile(soa, tile[lane]);
+            stage_tile(soa, tile[lane], st);
             __builtin_amdgcn_wave_barrier();
             uint32_t m0, m1;
             scan_tile(soa, q, st, m0, m1);

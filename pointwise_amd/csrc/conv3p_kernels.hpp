@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
             while (todo) {
                 const int ct = base + __builtin_ctzll(todo);
                 todo &= todo - 1;
-                stage_tile(soa, rec);
+                stage_tile(soa, rec, st);
                 if (todo) rec = cloud_pts[(size_t)(base + __builtin_ctzll(todo)) * kTile + lane];   // prefetch
                 __builtin_amdgcn_wave_barrier();
                 uint32_t m0, m1;
