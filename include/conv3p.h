@@ -119,7 +119,15 @@ typedef struct conv3p_cache_config {
                             A cloud that needs more is still handled correctly (slow path).        */
     int max_Cin;         /* largest channel counts of a backward call (sizes the scratch for the   */
     int max_Cout;        /*   per-workgroup grad_filter partials)                                    */
+    int flags;           /* CONV3P_CACHE_* bits below                                                */
 } conv3p_cache_config;
+
+/* Caller's promise for THIS call: `points` holds exactly the bytes it held at the previous *_cached_* call
+ * on this cache (e.g. the later layers of a model step, all fed by one points tensor).  The library then
+ * skips the content hash and, for a stencil it has already built since the last un-hinted call, the search
+ * launches as well.  Without the flag every call re-validates on the device (always safe).  A wrong promise
+ * gives results for the previous clouds. */
+#define CONV3P_CACHE_POINTS_UNCHANGED 1
 
 size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_config *cfg);
 /* Drop the host-side bookkeeping of a cache buffer (call before freeing it). */

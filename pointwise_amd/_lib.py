@@ -19,6 +19,7 @@ ERR_NO_DEVICE = 5
 PASS_FORWARD = 0
 PASS_BACKWARD = 1
 PASS_NEIGHBOR_COUNT = 2
+CACHE_POINTS_UNCHANGED = 1
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -40,7 +41,8 @@ def _sig(real):
 
 class CacheConfig(ctypes.Structure):
     """conv3p_cache_config of include/conv3p.h."""
-    _fields_ = [("slots", _i), ("max_taps", _i), ("pairs_per_point", _i), ("max_Cin", _i), ("max_Cout", _i)]
+    _fields_ = [("slots", _i), ("max_taps", _i), ("pairs_per_point", _i), ("max_Cin", _i), ("max_Cout", _i),
+                ("flags", _i)]
 
 
 SYMBOLS = {

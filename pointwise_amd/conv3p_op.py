@@ -53,13 +53,19 @@ class NeighborCache:
 
     def __init__(self, B, N, dtype, device, slots=5, max_taps=27, pairs_per_point=0, max_cin=36, max_cout=41):
         lib = _lib.load()
-        self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout)
+        self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout, 0)
         self.key = (int(B), int(N), dtype, torch.device(device))
         esz = _SFX[dtype][2]
         self.nbytes = lib.conv3p_cache_bytes(esz, B, N, ctypes.byref(self.cfg))
         if self.nbytes == 0:
             raise Conv3pInvalidArgument("bad neighbour-cache configuration")
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+
+    def cfg_ptr(self, points_unchanged):
+        """Address of the config struct for one call; points_unchanged = the caller's promise that `points`
+        holds the same bytes as at the previous cached call (CONV3P_CACHE_POINTS_UNCHANGED)."""
+        self.cfg.flags = _lib.CACHE_POINTS_UNCHANGED if points_unchanged else 0
+        return ctypes.addressof(self.cfg)
 
     def fits(self, B, N, dtype, device, ntap, cin, cout):
         return (self.key == (int(B), int(N), dtype, torch.device(device)) and ntap <= self.cfg.max_taps
@@ -131,7 +137,7 @@ def _call(fn, *args):
     raise Conv3pRuntimeError(msg)
 
 
-def conv3p(points, input, filter, stride, voxel_size, cache=None):
+def conv3p(points, input, filter, stride, voxel_size, cache=None, points_unchanged=False):
     """Conv3p forward.  points (B,N,3), input (B,N,Cin), filter (fz,fy,fx,Cin,Cout), stride [sx,sy,sz]
     (int32[3]), voxel_size T[1] -> output (B,N,Cout).  Mirrors conv3p_module.conv3p
     (/root/reference/pointcnn2_acsd.py:12-13).  cache (optional, not in the reference): a NeighborCache."""
@@ -150,7 +156,7 @@ def conv3p(points, input, filter, stride, voxel_size, cache=None):
             stream = torch.cuda.current_stream(dev)
             _call(getattr(lib, "conv3p_forward_cached_" + sfx), points.data_ptr(), input.data_ptr(),
                   filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx,
-                  out.data_ptr(), cache.buf.data_ptr(), cache.nbytes, ctypes.addressof(cache.cfg),
+                  out.data_ptr(), cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(points_unchanged),
                   stream.cuda_stream)
         else:
             need = lib.conv3p_workspace_bytes(_lib.PASS_FORWARD, esz, B, N, Cin, Cout, fz, fy, fx)
@@ -161,7 +167,8 @@ def conv3p(points, input, filter, stride, voxel_size, cache=None):
     return out
 
 
-def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_filter_out=None, cache=None):
+def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_filter_out=None, cache=None,
+                points_unchanged=False):
     """Conv3pGrad -> (grad_input, grad_filter).  Mirrors conv3p_module.conv3p_grad
     (/root/reference/pointcnn2_acsd.py:30; schema register_op.cpp:63-75).
     grad_filter_out (optional, not in the reference): a contiguous tensor shaped like filter to write
@@ -193,7 +200,7 @@ def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_
             _call(getattr(lib, "conv3p_backward_cached_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
                   input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
                   Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
-                  ctypes.addressof(cache.cfg), stream.cuda_stream)
+                  cache.cfg_ptr(points_unchanged), stream.cuda_stream)
         else:
             need = lib.conv3p_workspace_bytes(_lib.PASS_BACKWARD, esz, B, N, Cin, Cout, fz, fy, fx)
             ws, stream = _workspace(dev, need)

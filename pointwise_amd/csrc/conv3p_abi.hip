@@ -162,6 +162,8 @@ template <typename T> struct Layout {
         PairEntry *pairs;
     };
     std::vector<Slot> slot;
+    uint32_t *cursor_all;   // [nslots][B]
+    int nclouds;
     uint32_t pairs_per_cloud;
     int gtiles, ngroups;
     // per-call scratch
@@ -188,11 +190,13 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
     if ((size_t)B * ppc > 0xFFFFFFF0ull) ppc = B ? 0xFFFFFFF0ull / (size_t)B : 0;
     L.pairs_per_cloud = (uint32_t)ppc;
     L.slot.resize(nslots);
+    L.nclouds = B;
+    L.cursor_all = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * nslots));
     for (int s = 0; s < nslots; ++s) {
         auto &S = L.slot[s];
         S.built_version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
         S.rebuilt = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
-        S.cursor = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
+        S.cursor = L.cursor_all ? L.cursor_all + (size_t)s * B : nullptr;
         S.built_tag = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)B));
         S.count = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)B * N * ntap_max));
         S.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups));
@@ -245,6 +249,9 @@ template <typename T> struct Call {
     int slot;
     CacheCtl cc;
     hipStream_t s;
+    bool evicted_hinted = false;   // slot re-assigned to a new stencil while prep is skipped: reset its allocators
+    bool skip_prep = false;     // caller promised unchanged points
+    bool skip_search = false;   // ... and this slot's lists were already enqueued for them
 };
 
 template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned long long tag, uint32_t epoch, int force)
@@ -256,6 +263,9 @@ template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned l
     cc.built_tag = L.slot[slot].built_tag;
     cc.rebuilt = L.slot[slot].rebuilt;
     cc.cursor = L.slot[slot].cursor;
+    cc.cursor_all = L.cursor_all;
+    cc.nslots = (int)L.slot.size();
+    cc.nclouds = L.nclouds;
     cc.tag = tag;
     cc.epoch = epoch;
     cc.pairs_per_cloud = L.pairs_per_cloud;
@@ -265,6 +275,12 @@ template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned l
 
 template <typename T> int run_prep(const T *points, const Call<T> &c)
 {
+    if (c.skip_prep) {
+        if (c.evicted_hinted)   // prep_sort_kernel would have done this for an un-hinted call
+            return hipMemsetAsync(c.L.slot[c.slot].cursor, 0, sizeof(uint32_t) * (size_t)c.d.B, c.s) == hipSuccess
+                       ? CONV3P_OK : CONV3P_ERR_LAUNCH;
+        return CONV3P_OK;
+    }
     const Dims &d = c.d;
     Scope sc(K_PREP, c.s);
     if (d.N <= 16384 && d.N > kTile) {
@@ -286,6 +302,7 @@ template <typename T> int run_prep(const T *points, const Call<T> &c)
 // search (+ finalise when pair lists are wanted).  count: where the populations go.
 template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
+    if (c.skip_search && with_pairs) return CONV3P_OK;
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
@@ -376,7 +393,9 @@ struct CacheHost {
     int B = -1, N = -1, elem = 0, ntap_max = 0, nslots = 0, ppp = 0;
     std::vector<unsigned long long> tags;
     std::vector<uint64_t> stamp;
+    std::vector<uint64_t> built_gen;   // generation in which the slot's search was last enqueued
     uint64_t clock = 0;
+    uint64_t gen = 0;                  // bumped by every call that does not carry CONV3P_CACHE_POINTS_UNCHANGED
     uint32_t epoch = 0;
 };
 std::mutex g_cache_mu;
@@ -389,6 +408,7 @@ struct Where {
     bool persistent;
     int nslots, ntap_max, ppp;
     size_t scratch_cap;   // persistent: bytes of scratch the layout was sized with
+    int flags;            // CONV3P_CACHE_* of this call
 };
 
 template <typename T>
@@ -417,7 +437,10 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
         h.B = d.B; h.N = d.N; h.elem = (int)sizeof(T); h.ntap_max = ntap_max; h.nslots = wh.nslots; h.ppp = wh.ppp;
         h.tags.assign(wh.nslots, 0ull);
         h.stamp.assign(wh.nslots, 0ull);
+        h.built_gen.assign(wh.nslots, 0ull);
     }
+    const bool hinted = (wh.flags & CONV3P_CACHE_POINTS_UNCHANGED) != 0 && h.gen != 0;
+    if (!hinted) h.gen += 1;
     int slot = -1;
     for (int i = 0; i < h.nslots; ++i)
         if (h.tags[i] == tag) slot = i;
@@ -426,7 +449,12 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
         for (int i = 1; i < h.nslots; ++i)
             if (h.stamp[i] < h.stamp[slot]) slot = i;
         h.tags[slot] = tag;
+        h.built_gen[slot] = 0;
     }
+    c.skip_prep = hinted;
+    c.evicted_hinted = hinted && h.built_gen[slot] == 0 && c.L.slot[slot].cursor != nullptr;
+    c.skip_search = hinted && h.built_gen[slot] == h.gen;
+    h.built_gen[slot] = h.gen;
     h.stamp[slot] = ++h.clock;
     h.epoch += 1;
     if (h.epoch == 0) h.epoch = 1;
@@ -516,7 +544,7 @@ int count_impl(const T *points, const int32_t *stride, T voxel, int B, int N, in
     if (!points || !count) return CONV3P_ERR_INVALID_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Call<T> c;
-    const Where wh{ws, ws_bytes, false, 1, d.ntap, 0, 0};   // populations only: no pair storage
+    const Where wh{ws, ws_bytes, false, 1, d.ntap, 0, 0, 0};   // populations only: no pair storage
     TRY(begin_call<T>(c, d, stride, voxel, 0, wh, s));
     TRY(run_prep<T>(points, c));
     return run_search<T>(c, count, false);
@@ -556,13 +584,13 @@ size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, in
     return (size_t)max_taps * max_Cin * max_Cout * (size_t)grid_of(make_blockmap(d)) * (size_t)elem;
 }
 
-Where stateless(void *ws, size_t bytes) { return Where{ws, bytes, false, 1, 0, kDefaultPairsPerPoint, 0}; }
+Where stateless(void *ws, size_t bytes) { return Where{ws, bytes, false, 1, 0, kDefaultPairsPerPoint, 0, 0}; }
 
 Where persistent(int elem, int B, int N, void *cache, size_t bytes, int slots, int max_taps, int ppp, int max_Cin,
-                 int max_Cout)
+                 int max_Cout, int flags)
 {
     return Where{cache, bytes, true, slots, max_taps, ppp > 0 ? ppp : kDefaultPairsPerPoint,
-                 cache_scratch_bytes(elem, B, N, max_taps, max_Cin, max_Cout)};
+                 cache_scratch_bytes(elem, B, N, max_taps, max_Cin, max_Cout), flags};
 }
 
 bool cache_cfg_ok(const conv3p_cache_config *cfg)
@@ -633,7 +661,7 @@ int conv3p_backward_f64(BWD_ARGS(double), void *workspace, size_t workspace_byte
 #define CACHE_ARGS void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream
 #define CACHE_WHERE(elem)                                                                                      \
     persistent(elem, B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point, cfg->max_Cin,   \
-               cfg->max_Cout)
+               cfg->max_Cout, cfg->flags)
 int conv3p_forward_cached_f32(FWD_ARGS(float), CACHE_ARGS)
 {
     if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;

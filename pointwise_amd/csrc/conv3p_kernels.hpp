@@ -36,7 +36,9 @@ struct CacheCtl {
     uint32_t *built_version;         // [B] of the slot in use
     unsigned long long *built_tag;   // [B]
     uint32_t *rebuilt;               // [B]
-    uint32_t *cursor;                // [B]
+    uint32_t *cursor;                // [B] of the slot in use
+    uint32_t *cursor_all;            // [nslots][B]: all slots' allocators (contiguous)
+    int nslots, nclouds;
     unsigned long long tag;
     uint32_t epoch;
     uint32_t pairs_per_cloud;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const T *__restrict__ points,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cc.version[blockIdx.y] += 1;
         cc.hash[blockIdx.y] = 0;
-        cc.cursor[blockIdx.y] = 0;
+        for (int sl = 0; sl < cc.nslots; ++sl) cc.cursor_all[(size_t)sl * cc.nclouds + blockIdx.y] = 0;
     }
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -148,6 +150,8 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
             if (!same) {
                 cc.hash[b] = t;
                 cc.version[b] += 1;
+                // every slot's lists of this cloud are stale now: their allocators restart from empty
+                for (int sl = 0; sl < cc.nslots; ++sl) cc.cursor_all[(size_t)sl * cc.nclouds + b] = 0;
             }
             // the slot about to be used must allocate from an empty region if it is going to rebuild
             const bool valid = same && cc.built_version[b] == cc.version[b] && cc.built_tag[b] == cc.tag;

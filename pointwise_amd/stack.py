@@ -68,12 +68,14 @@ class Conv3pStack:
         acts, x = [], features
         for li in range(4):
             _, _, s = self.layers[li]
-            x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL, cache=cache))
+            x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL, cache=cache,
+                                  points_unchanged=li > 0))   # layer 0 re-validates, the rest reuse
             acts.append(x)
         concat = None
         if self.num_class is not None:
             concat = torch.cat(acts, dim=2)
-            acts.append(op.selu(op.conv3p(points, concat, self.filters[4], (1, 1, 1), VOXEL, cache=cache)))
+            acts.append(op.selu(op.conv3p(points, concat, self.filters[4], (1, 1, 1), VOXEL, cache=cache,
+                                          points_unchanged=True)))
         self._saved = (points, features, acts, concat)
         return acts
 
@@ -85,7 +87,7 @@ class Conv3pStack:
         if self.num_class is not None:
             g = op.selu_grad(acts[4], upstream[0])
             dconcat, _ = op.conv3p_grad(g, points, concat, self.filters[4], (1, 1, 1), VOXEL,
-                                        grad_filter_out=self.grad_views[4], cache=cache)
+                                        grad_filter_out=self.grad_views[4], cache=cache, points_unchanged=True)
             ext = [dconcat[:, :, HIDDEN * i:HIDDEN * (i + 1)].contiguous() for i in range(4)]
         else:
             ext = list(upstream)
@@ -95,7 +97,7 @@ class Conv3pStack:
             g = op.selu_grad(acts[li], ext[li], carry)
             x_in = acts[li - 1] if li > 0 else features
             carry, _ = op.conv3p_grad(g, points, x_in, self.filters[li], (s, s, s), VOXEL,
-                                      grad_filter_out=self.grad_views[li], cache=cache)
+                                      grad_filter_out=self.grad_views[li], cache=cache, points_unchanged=True)
         return carry, self.fused_grad
 
 

@@ -336,3 +336,22 @@ def test_results_are_bitwise_reproducible(dev):
     b = _both(dev, None, P, X, W, dY, (2, 2, 2))
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_stack_with_cache_hints_over_changing_batches(dev):
+    """What bench.py does: one Conv3pStack (neighbour cache + POINTS_UNCHANGED hints inside a step) fed a
+    different batch every step must give exactly what a cache-less stack gives, step after step."""
+    B, N = 4, 512
+    cached = stack.Conv3pStack(3, None, device=dev, seed=5, use_cache=True)
+    plain = stack.Conv3pStack(3, None, device=dev, seed=5, use_cache=False)
+    ups = [torch.from_numpy(synth.upstream_grad(B, N, 9, 900 + i)).to(dev) for i in range(4)]
+    batches = [torch.from_numpy(synth.modelnet_like(B, N, seed=910 + i)).to(dev) for i in range(3)]
+    for step in range(7):
+        P = batches[step % 3]
+        a1 = cached.forward(P, P)
+        dx1, f1 = cached.backward(ups)
+        a2 = plain.forward(P, P)
+        dx2, f2 = plain.backward(ups)
+        for u, v in zip(a1, a2):
+            assert torch.equal(u, v)
+        assert torch.equal(dx1, dx2) and torch.equal(f1, f2)
