@@ -152,6 +152,17 @@ int conv3p_backward_cached_f64(const double *grad_out, const double *points, con
                                double *grad_input, double *grad_filter, void *cache,
                                size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
 
+/* Build (or re-validate) the geometry of one stencil without running an op: a later forward / backward
+ * with the same points and stencil finds its lists ready.  Lets a caller enqueue the searches of a model's
+ * later layers on a second stream while the first layers' accumulation kernels run (the search is
+ * VALU-bound, the accumulation gather-latency-bound; they overlap well). */
+int conv3p_cache_prepare_f32(const float *points, const int32_t *stride_xyz, float voxel_size, int B,
+                             int N, int fz, int fy, int fx, void *cache, size_t cache_bytes,
+                             const conv3p_cache_config *cfg, void *stream);
+int conv3p_cache_prepare_f64(const double *points, const int32_t *stride_xyz, double voxel_size, int B,
+                             int N, int fz, int fy, int fx, void *cache, size_t cache_bytes,
+                             const conv3p_cache_config *cfg, void *stream);
+
 /* Per-point, per-tap neighbour populations, int32 (B, N, fz*fy*fx) on the device.
  * Restates Grid::neighbor_count / kernelBuildNeighborCount
  * (tf_conv3p_atrous.cpp:306-379 / tf_conv3p_atrous.cu:288-343): the intermediate both

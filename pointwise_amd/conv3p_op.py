@@ -210,6 +210,26 @@ def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_
     return dx, dw
 
 
+def cache_prepare(points, filter_zyx, stride, voxel_size, cache, points_unchanged=False, stream=None):
+    """Build / re-validate the geometry of one stencil in `cache` (conv3p_cache_prepare_*), on `stream`
+    (default: the current stream)."""
+    lib = _lib.load()
+    _require(points.dim() == 3 and points.shape[2] == 3, "Conv3p expects (batch_size, num_points, 3) points shape")
+    dev = _check_device(points)
+    sfx, creal, esz = _SFX[points.dtype]
+    s3 = _stride_list(stride)
+    vox = _voxel_value(voxel_size)
+    B, N, _ = points.shape
+    fz, fy, fx = [int(v) for v in filter_zyx]
+    if not cache.fits(B, N, points.dtype, dev, fz * fy * fx, 0, 0):
+        raise Conv3pInvalidArgument("neighbour cache does not fit these clouds")
+    with torch.cuda.device(dev):
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        _call(getattr(lib, "conv3p_cache_prepare_" + sfx), points.data_ptr(), ctypes.cast(s3, ctypes.c_void_p),
+              creal(vox), B, N, fz, fy, fx, cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(points_unchanged),
+              st.cuda_stream)
+
+
 def neighbor_count(points, filter_zyx, stride, voxel_size):
     """int32 (B, N, fz*fy*fx) per-tap neighbour populations (the op's normaliser), for exact parity checks."""
     lib = _lib.load()

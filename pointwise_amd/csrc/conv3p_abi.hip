@@ -180,7 +180,15 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
     size_t off = 0;
     char *p = static_cast<char *>(base);
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
-    L.gtiles = ntiles < kGroupTiles ? (ntiles > 0 ? ntiles : 1) : kGroupTiles;
+    // hit masks take 512 B per candidate tile of a group; leave room for the [taps][65] populations
+    int gmax = kGroupTiles;
+    {
+        const size_t fixed = (size_t)ntap_max * kCntStride * 4 + 16 * 1024;
+        const size_t room = fixed < 150 * 1024 ? 150 * 1024 - fixed : 0;
+        const int fit = (int)(room / 516);
+        if (fit < gmax) gmax = fit < 4 ? 4 : fit;
+    }
+    L.gtiles = ntiles < gmax ? (ntiles > 0 ? ntiles : 1) : gmax;
     L.ngroups = ntiles > 0 ? (ntiles + L.gtiles - 1) / L.gtiles : 1;
     L.hash = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)B));
     L.version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
@@ -309,7 +317,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
     const size_t lds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) +
                        a16((size_t)c.L.gtiles * 64 * 8) + a16((size_t)c.L.gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
                        a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
-    if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
+    if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;   // very large filters (> ~340 taps): populations alone exceed LDS
     const BlockMap bm = make_blockmap(d);
     {
         Scope sc(K_SEARCH, c.s);
@@ -489,6 +497,21 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     }
     TRY(zero_async(output, out_elems * sizeof(T), s));                   // .cpp:451
     return launch_forward<T, 0, 0>(c, input, filter, output);
+}
+
+// geometry only: what a later forward / backward with the same points + stencil will find ready
+template <typename T>
+int prepare_impl(const T *points, const int32_t *stride, T voxel, int B, int N, int fz, int fy, int fx,
+                 const Where &wh, void *stream)
+{
+    Dims d{B, N, 0, 0, fz, fy, fx, 0, 0};
+    TRY(check(d, stride, (double)voxel, false));
+    if ((size_t)B * N == 0) return CONV3P_OK;
+    if (!points) return CONV3P_ERR_INVALID_ARGUMENT;
+    Call<T> c;
+    TRY(begin_call<T>(c, d, stride, voxel, 0, wh, static_cast<hipStream_t>(stream)));
+    TRY(run_prep<T>(points, c));
+    return run_search<T>(c, c.L.slot[c.slot].count, true);
 }
 
 template <typename T>
@@ -681,6 +704,19 @@ int conv3p_backward_cached_f64(BWD_ARGS(double), CACHE_ARGS)
 {
     if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
     return backward_impl<double>(BWD_PASS, CACHE_WHERE(8), stream);
+}
+
+int conv3p_cache_prepare_f32(const float *points, const int32_t *stride_xyz, float voxel_size, int B, int N,
+                             int fz, int fy, int fx, CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return prepare_impl<float>(points, stride_xyz, voxel_size, B, N, fz, fy, fx, CACHE_WHERE(4), stream);
+}
+int conv3p_cache_prepare_f64(const double *points, const int32_t *stride_xyz, double voxel_size, int B, int N,
+                             int fz, int fy, int fx, CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return prepare_impl<double>(points, stride_xyz, voxel_size, B, N, fz, fy, fx, CACHE_WHERE(8), stream);
 }
 
 int conv3p_neighbor_count_f32(const float *points, const int32_t *stride_xyz, float voxel_size, int B,

@@ -25,11 +25,15 @@ HIDDEN = 9
 
 class Conv3pStack:
     def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234,
-                 use_cache=True):
+                 use_cache=True, overlap_search=True):
         """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers).
         use_cache: keep the geometry (sorted points, populations, neighbour lists) of each layer's stencil in
         a NeighborCache so that the search runs once per (points, stride) instead of once per op call."""
         self.use_cache = use_cache
+        # enqueue every layer's neighbour search on a second stream at the start of forward(): the search of
+        # layer l+1 (VALU-bound) then runs while layer l accumulates (gather-latency-bound)
+        self.overlap_search = overlap_search and use_cache
+        self._side = None
         self._cache = None
         self.device = torch.device(device)
         self.dtype = dtype
@@ -63,17 +67,36 @@ class Conv3pStack:
                                            max_cin=cmax, max_cout=cmax)
         return self._cache
 
+    def _enqueue_searches(self, points, cache):
+        """All layers' geometry on the side stream; returns one event per layer."""
+        main = torch.cuda.current_stream(points.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=points.device)
+        self._side.wait_stream(main)                       # `points` is ready on the main stream
+        events = []
+        for li, (_, _, s) in enumerate(self.layers):
+            op.cache_prepare(points, (3, 3, 3), (s, s, s), VOXEL, cache, points_unchanged=li > 0, stream=self._side)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            events.append(ev)
+        return main, events
+
     def forward(self, points, features):
         cache = self._cache_for(points)
+        main, events = (self._enqueue_searches(points, cache) if self.overlap_search else (None, None))
         acts, x = [], features
         for li in range(4):
             _, _, s = self.layers[li]
+            if events is not None:
+                main.wait_event(events[li])
             x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL, cache=cache,
-                                  points_unchanged=li > 0))   # layer 0 re-validates, the rest reuse
+                                  points_unchanged=li > 0 or events is not None))   # first call re-validates
             acts.append(x)
         concat = None
         if self.num_class is not None:
             concat = torch.cat(acts, dim=2)
+            if events is not None:
+                main.wait_event(events[4])
             acts.append(op.selu(op.conv3p(points, concat, self.filters[4], (1, 1, 1), VOXEL, cache=cache,
                                           points_unchanged=True)))
         self._saved = (points, features, acts, concat)
