@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not enqueue the next batch's neighbour search under the current batch's backward")
     args = ap.parse_args()
 
     rank, world, local = distributed.init_from_env()
@@ -120,10 +122,17 @@ def main():
     st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234)
     counter = [0]
 
+    prefetch = not args.no_prefetch
+
     def step():
         i = counter[0] % NBATCH
         counter[0] += 1
         st.forward(tPs[i], tXs[i])
+        if prefetch:
+            # the next batch's geometry (1 sort + 4 searches) goes to the side stream now and runs under this
+            # batch's backward, as a data-loader-fed training loop would do.  Every step still performs exactly
+            # one full geometry build, one forward and one backward inside the timed region.
+            st.prefetch(tPs[(i + 1) % NBATCH])
         dx, fused = st.backward(ups)
         distributed.allreduce_weight_grads(fused)
         return dx, fused
@@ -191,6 +200,8 @@ def main():
                "config": {"workload": "cfg2 ModelNet40-shaped: B=32 clouds/GPU x N=2048, pointcnn2_acsd conv3p "
                                       "stack 3->9 s1, 9->9 s2, 9->9 s3, 9->9 s4 (+SELU), forward+backward, "
                                       "a different batch every step"
+                                      + (", next batch's neighbour search enqueued on a side stream under the "
+                                         "current backward" if prefetch else "")
                                       + (", fused RCCL all-reduce of 7290 weight grads" if world > 1 else ""),
                           "global_batch": B_PER_GPU * world, "points_per_cloud": N_POINTS,
                           "parallelism": "dp%d" % world},

@@ -35,6 +35,9 @@ class Conv3pStack:
         self.overlap_search = overlap_search and use_cache
         self._side = None
         self._cache = None
+        self._caches = [None, None]    # two neighbour caches: the batch in flight and the prefetched one
+        self._which = 0
+        self._prefetched = None        # (tensor, cache index, events) of the last prefetch()
         self.device = torch.device(device)
         self.dtype = dtype
         self.num_class = num_class
@@ -57,15 +60,33 @@ class Conv3pStack:
             o += n
         self._saved = None
 
+    def _cache_slot(self, idx, points):
+        B, N = points.shape[0], points.shape[1]
+        cmax = max(max(ci, co) for ci, co, _ in self.layers)
+        c = self._caches[idx]
+        if c is None or not c.fits(B, N, points.dtype, points.device, 27, cmax, cmax):
+            c = op.NeighborCache(B, N, points.dtype, points.device, slots=len(self.layers), max_taps=27,
+                                 max_cin=cmax, max_cout=cmax)
+            self._caches[idx] = c
+        return c
+
     def _cache_for(self, points):
         if not self.use_cache:
             return None
-        B, N = points.shape[0], points.shape[1]
-        cmax = max(max(ci, co) for ci, co, _ in self.layers)
-        if self._cache is None or not self._cache.fits(B, N, points.dtype, points.device, 27, cmax, cmax):
-            self._cache = op.NeighborCache(B, N, points.dtype, points.device, slots=len(self.layers), max_taps=27,
-                                           max_cin=cmax, max_cout=cmax)
+        self._cache = self._cache_slot(self._which, points)
         return self._cache
+
+    def prefetch(self, points):
+        """Software pipelining across steps: enqueue the geometry (sort + every layer's neighbour search) of the
+        NEXT batch on the side stream, typically right after forward() of the current batch, so that it runs under
+        the current batch's backward.  Geometry depends on `points` only.  The caller must not modify `points`
+        between prefetch() and the forward() that consumes it (that forward trusts the prefetch)."""
+        if not self.use_cache:
+            return
+        idx = 1 - self._which
+        cache = self._cache_slot(idx, points)
+        _, events = self._enqueue_searches(points, cache)
+        self._prefetched = (points, idx, events)
 
     def _enqueue_searches(self, points, cache):
         """All layers' geometry on the side stream; returns one event per layer."""
@@ -82,8 +103,16 @@ class Conv3pStack:
         return main, events
 
     def forward(self, points, features):
-        cache = self._cache_for(points)
-        main, events = (self._enqueue_searches(points, cache) if self.overlap_search else (None, None))
+        pf = self._prefetched
+        if pf is not None and pf[0] is points and self.use_cache:
+            # geometry was enqueued by prefetch(): switch to that cache, wait for its per-layer events
+            self._which = pf[1]
+            cache = self._cache = self._caches[pf[1]]
+            main, events = torch.cuda.current_stream(points.device), pf[2]
+            self._prefetched = None
+        else:
+            cache = self._cache_for(points)
+            main, events = (self._enqueue_searches(points, cache) if self.overlap_search else (None, None))
         acts, x = [], features
         for li in range(4):
             _, _, s = self.layers[li]
@@ -106,7 +135,7 @@ class Conv3pStack:
         """upstream: classification -> list of 4 tensors dL/d(act_l) (the slices of dL/dconcat);
         segmentation -> [dL/dlogits_act].  Returns (dL/dfeatures, fused weight-gradient buffer)."""
         points, features, acts, concat = self._saved
-        cache = self._cache_for(points)
+        cache = self._cache if self.use_cache else None
         if self.num_class is not None:
             g = op.selu_grad(acts[4], upstream[0])
             dconcat, _ = op.conv3p_grad(g, points, concat, self.filters[4], (1, 1, 1), VOXEL,

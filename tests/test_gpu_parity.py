@@ -349,6 +349,8 @@ def test_stack_with_cache_hints_over_changing_batches(dev):
     for step in range(7):
         P = batches[step % 3]
         a1 = cached.forward(P, P)
+        if step % 2 == 0:
+            cached.prefetch(batches[(step + 1) % 3])      # cross-step pipelining, every other step
         dx1, f1 = cached.backward(ups)
         a2 = plain.forward(P, P)
         dx2, f2 = plain.backward(ups)
