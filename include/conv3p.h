@@ -115,7 +115,7 @@ int conv3p_backward_f64(const double *grad_out, const double *points, const doub
 typedef struct conv3p_cache_config {
     int slots;           /* stencils cached simultaneously (1..64)                                   */
     int max_taps;        /* largest fz*fy*fx that will be used with this cache (27 for 3x3x3)        */
-    int pairs_per_point; /* pair-list capacity per point, averaged over a cloud; 0 = default (128).
+    int pairs_per_point; /* pair-list capacity per point, averaged over a cloud; 0 = default (256).
                             A cloud that needs more is still handled correctly (slow path).        */
     int max_Cin;         /* largest channel counts of a backward call (sizes the scratch for the   */
     int max_Cout;        /*   per-workgroup grad_filter partials)                                    */

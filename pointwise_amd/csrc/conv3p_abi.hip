@@ -28,10 +28,12 @@ constexpr size_t kAlign = 256;
 inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 // ----------------------------------------------------------------------------- profiling
-enum Kind { K_PREP = 0, K_SEARCH, K_FINALISE, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET, K_NKINDS };
+enum Kind { K_PREP = 0, K_SEARCH, K_FINALISE, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET,
+            K_DEEP_GEMM, K_DEEP_DW, K_TRANSPOSE, K_NKINDS };
 const char *const kKindName[K_NKINDS] = {"prep_kernel", "search_kernel", "finalise_kernel", "forward_kernel",
                                          "backward_kernel", "reduce_partials_kernel", "selu_kernel",
-                                         "selu_grad_kernel", "memset"};
+                                         "selu_grad_kernel", "memset", "deep_gemm_kernel", "deep_dw_kernel",
+                                         "transpose_filter_kernel"};
 struct Prof {
     std::mutex mu;
     bool on = false;
@@ -145,7 +147,7 @@ inline unsigned grid_of(const BlockMap &m) { return 8u * (unsigned)m.rounds * (u
 // One layout serves both the per-call workspace (1 slot, rebuilt every call) and the persistent
 // neighbour cache (several slots).  Everything a slot holds depends only on (points, stencil).
 constexpr int kGroupTiles = 128;      // candidate tiles per search group (64 KiB of hit masks in LDS)
-constexpr int kDefaultPairsPerPoint = 128;
+constexpr int kDefaultPairsPerPoint = 256;   // 16-B records; room-like clouds reach ~170 neighbours/point
 
 template <typename T> struct Layout {
     // per cloud, independent of the stencil
@@ -231,11 +233,25 @@ inline bool small_shape(int elem, int cin, int cout)
     return false;
 }
 
+inline bool deep_shape(int elem, int cin, int cout);
+struct DeepScratch;
+size_t deep_scratch_bytes(const Dims &d, size_t pair_slots);
+
 size_t backward_scratch_bytes(const Dims &d, int elem)
 {
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
+    if (deep_shape(elem, d.Cin, d.Cout)) {
+        size_t ppc = (size_t)d.N * kDefaultPairsPerPoint;
+        return deep_scratch_bytes(d, (size_t)d.B * ppc);
+    }
     const size_t slots = small_shape(elem, d.Cin, d.Cout) ? (size_t)grid_of(make_blockmap(d)) : 1;
     return nw * slots * (size_t)elem;
+}
+
+size_t forward_scratch_bytes(const Dims &d, int elem)
+{
+    if (deep_shape(elem, d.Cin, d.Cout)) return deep_scratch_bytes(d, (size_t)d.B * d.N * kDefaultPairsPerPoint);
+    return 0;
 }
 
 int hip_ok()
@@ -257,6 +273,7 @@ template <typename T> struct Call {
     int slot;
     CacheCtl cc;
     hipStream_t s;
+    bool deep_scratch_ok = false;  // the scratch region can hold the deep path's side arrays
     bool evicted_hinted = false;   // slot re-assigned to a new stencil while prep is skipped: reset its allocators
     bool skip_prep = false;     // caller promised unchanged points
     bool skip_search = false;   // ... and this slot's lists were already enqueued for them
@@ -337,7 +354,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
 }
 
 template <typename T, int CI, int CO>
-int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output)
+int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output, const uint8_t *only_flagged = nullptr)
 {
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
@@ -353,12 +370,13 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output)
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, d.Cin, d.Cout,
-                       bm, output);
+                       bm, output, only_flagged);
     return hip_ok();
 }
 
 template <typename T, int CI, int CO>
-int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T *filter, T *grad_input)
+int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T *filter, T *grad_input,
+                    T *partials = nullptr, const uint8_t *only_flagged = nullptr)
 {
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
@@ -376,15 +394,128 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
-                       d.Cin, d.Cout, bm, grad_input, c.L.partials);
+                       d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged);
     return hip_ok();
 }
+
+
 
 int zero_async(void *p, size_t bytes, hipStream_t s)
 {
     if (bytes == 0) return CONV3P_OK;
     Scope sc(K_MEMSET, s);
     return hipMemsetAsync(p, 0, bytes, s) == hipSuccess ? CONV3P_OK : CONV3P_ERR_LAUNCH;
+}
+
+// ----------------------------------------------------------------------------- deep-channel path
+// (Cin, Cout) pairs served by the matrix-core kernels of conv3p_deep.hpp (fp32 only).
+#define CONV3P_DEEP_SHAPES(X) X(128, 256) X(32, 64) X(64, 64) X(64, 128) X(128, 128)
+
+inline bool deep_shape(int elem, int cin, int cout)
+{
+    if (elem != 4) return false;
+#define X(ci, co) if (cin == ci && cout == co) return true;
+    CONV3P_DEEP_SHAPES(X)
+#undef X
+    return false;
+}
+
+struct DeepScratch {   // carved from the per-call scratch region
+    float *wt;             // filter transposed [F][Cout][Cin]
+    uint16_t *bucket_order;   // per pair slot: centre-major, tap-sorted record order
+    uint32_t *tap_order;      // per pair slot: tile tap-major record order (backward)
+    uint32_t *tap_off;     // [tiles][F+1]
+    uint8_t *tile_flag;    // [tiles]
+    float *partials;       // [nchunks + 1][F*Cin*Cout]
+    int nchunks;
+    size_t bytes;
+};
+
+DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
+{
+    DeepScratch s{};
+    size_t off = 0;
+    char *p = static_cast<char *>(base);
+    auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
+    const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
+    const int slices = d.Cout / 64;
+    s.nchunks = 512 / (d.ntap * slices) > 1 ? 512 / (d.ntap * slices) : 1;
+    if (s.nchunks > 16) s.nchunks = 16;
+    s.wt = reinterpret_cast<float *>(take(nw * 4));
+    s.bucket_order = reinterpret_cast<uint16_t *>(take(pair_slots * 2));
+    s.tap_order = reinterpret_cast<uint32_t *>(take(pair_slots * 4));
+    s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
+    s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
+    s.partials = reinterpret_cast<float *>(take(nw * 4 * (size_t)(s.nchunks + 1)));
+    s.bytes = off;
+    return s;
+}
+
+size_t deep_scratch_bytes(const Dims &d, size_t pair_slots) { return carve_deep(d, pair_slots, nullptr).bytes; }
+
+template <int KD, int ND, bool BWD>
+int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, float *out, const DeepScratch &ds)
+{
+    const Dims &d = c.d;
+    const auto &S = c.L.slot[c.slot];
+    const size_t lds = a16((size_t)64 * (KD + 1) * 4) + a16((size_t)64 * (d.ntap + 1) * 2) + 256 + 256 +
+                       a16((size_t)d.ntap * 4) + 256;
+    if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
+    const BlockMap bm = make_blockmap(d);
+    Scope sc(K_DEEP_GEMM, c.s);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_gemm_kernel<KD, ND, BWD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((deep_gemm_kernel<KD, ND, BWD>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs,
+                       S.segs, S.qsegs, src, Bm, d.N, d.ntiles, d.ntap, bm, out, ds.bucket_order, ds.tap_order,
+                       ds.tap_off, ds.tile_flag);
+    return hip_ok();
+}
+
+template <int CI, int CO>
+int deep_forward(const Call<float> &c, const float *input, const float *filter, float *output)
+{
+    const DeepScratch ds = carve_deep(c.d, (size_t)c.d.B * c.L.pairs_per_cloud, c.L.partials);
+    TRY((launch_deep_gemm<CI, CO, false>(c, input, filter, output, ds)));
+    // tiles the deep kernel could not take (pair buffer overflow): generic kernel, flagged tiles only
+    return launch_forward<float, 0, 0>(c, input, filter, output, ds.tile_flag);
+}
+
+template <int CI, int CO>
+int deep_backward(const Call<float> &c, const float *grad_out, const float *input, const float *filter,
+                  float *grad_input, float *grad_filter)
+{
+    const Dims &d = c.d;
+    const auto &S = c.L.slot[c.slot];
+    const size_t nw = (size_t)d.ntap * CI * CO;
+    const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials);
+    {
+        Scope sc(K_TRANSPOSE, c.s);
+        hipLaunchKernelGGL(transpose_filter_kernel, dim3((unsigned)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024)),
+                           dim3(256), 0, c.s, filter, d.ntap, CI, CO, ds.wt);
+    }
+    TRY(hip_ok());
+    // dX = sum_f' G_f' . W[f']^T  (K = Cout, N = Cin); also publishes the tap-major record order
+    TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds)));
+    {
+        const size_t lds = a16((size_t)64 * (CI + 1) * 4) + a16((size_t)64 * 65 * 4);
+        Scope sc(K_DEEP_DW, c.s);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_dw_kernel<CI, CO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(d.ntap, CO / 64, ds.nchunks), dim3(256), lds, c.s, c.L.pts,
+                           S.pairs, S.segs, ds.tap_order, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap,
+                           ds.nchunks, ds.partials);
+    }
+    TRY(hip_ok());
+    // flagged tiles: generic kernel adds into the zeroed rows / into the extra partial slot
+    float *extra = ds.partials + nw * (size_t)ds.nchunks;
+    TRY(zero_async(extra, nw * 4, c.s));
+    TRY((launch_backward<float, 0, 0>(c, grad_out, input, filter, grad_input, extra, ds.tile_flag)));
+    {
+        Scope sc(K_REDUCE, c.s);
+        hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3((unsigned)((nw + 63) / 64)), dim3(1024), 0, c.s,
+                           ds.partials, ds.nchunks + 1, nw, grad_filter);
+    }
+    return hip_ok();
 }
 
 int buf_check(const void *p, size_t have, size_t need)
@@ -431,6 +562,11 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     if (wh.persistent && scratch > wh.scratch_cap) return CONV3P_ERR_WORKSPACE;
     c.L = carve<T>(d.B, d.N, d.ntiles, ntap_max, wh.nslots, wh.ppp, wh.persistent ? wh.scratch_cap : scratch, wh.buf);
     TRY(buf_check(wh.buf, wh.bytes, c.L.bytes));
+    {
+        const size_t have = wh.persistent ? wh.scratch_cap : scratch;
+        c.deep_scratch_ok = deep_shape((int)sizeof(T), d.Cin, d.Cout) &&
+                            have >= deep_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
+    }
     const unsigned long long tag = stencil_tag(d, stride, (double)voxel, (int)sizeof(T));
     if (!wh.persistent) {
         c.slot = 0;
@@ -483,7 +619,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     if (!points || !output || (Cin > 0 && (!input || !filter))) return CONV3P_ERR_INVALID_ARGUMENT;
     if (Cin == 0) return zero_async(output, out_elems * sizeof(T), s);   // empty contraction
     Call<T> c;
-    TRY(begin_call<T>(c, d, stride, voxel, 0, wh, s));
+    TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T)), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     if constexpr (sizeof(T) == 4) {
@@ -494,6 +630,15 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     }
         CONV3P_SMALL_SHAPES(X)
 #undef X
+        if (c.L.ngroups == 1 && c.deep_scratch_ok) {
+#define X(ci, co)                                                                                    \
+    if (Cin == ci && Cout == co) {                                                                   \
+        int rc = deep_forward<ci, co>(c, input, filter, output);                                     \
+        if (rc != CONV3P_ERR_UNSUPPORTED) return rc;                                                 \
+    }
+            CONV3P_DEEP_SHAPES(X)
+#undef X
+        }
     }
     TRY(zero_async(output, out_elems * sizeof(T), s));                   // .cpp:451
     return launch_forward<T, 0, 0>(c, input, filter, output);
@@ -541,6 +686,15 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input);
         CONV3P_SMALL_SHAPES(X)
 #undef X
+        if (rc == CONV3P_ERR_UNSUPPORTED && c.L.ngroups == 1 && c.deep_scratch_ok) {
+#define X(ci, co)                                                                                    \
+    if (Cin == ci && Cout == co) {                                                                   \
+        int drc = deep_backward<ci, co>(c, grad_out, input, filter, grad_input, grad_filter);        \
+        if (drc != CONV3P_ERR_UNSUPPORTED) return drc;                                               \
+    }
+            CONV3P_DEEP_SHAPES(X)
+#undef X
+        }
     }
     if (rc == CONV3P_ERR_UNSUPPORTED) {
         nslots = 1;
@@ -601,10 +755,15 @@ size_t layout_bytes(int elem, int B, int N, int ntap, int nslots, int ppp, size_
                      : carve<double>(B, N, ntiles, ntap, nslots, ppp, scratch, nullptr).bytes;
 }
 
-size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, int max_Cout)
+size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, int max_Cout, int ppp)
 {
     Dims d{B, N, max_Cin, max_Cout, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};
-    return (size_t)max_taps * max_Cin * max_Cout * (size_t)grid_of(make_blockmap(d)) * (size_t)elem;
+    size_t b = (size_t)max_taps * max_Cin * max_Cout * (size_t)grid_of(make_blockmap(d)) * (size_t)elem;
+    if (deep_shape(elem, max_Cin, max_Cout)) {
+        const size_t deep = deep_scratch_bytes(d, (size_t)B * N * (size_t)ppp);
+        if (deep > b) b = deep;
+    }
+    return b;
 }
 
 Where stateless(void *ws, size_t bytes) { return Where{ws, bytes, false, 1, 0, kDefaultPairsPerPoint, 0, 0}; }
@@ -613,7 +772,7 @@ Where persistent(int elem, int B, int N, void *cache, size_t bytes, int slots, i
                  int max_Cout, int flags)
 {
     return Where{cache, bytes, true, slots, max_taps, ppp > 0 ? ppp : kDefaultPairsPerPoint,
-                 cache_scratch_bytes(elem, B, N, max_taps, max_Cin, max_Cout), flags};
+                 cache_scratch_bytes(elem, B, N, max_taps, max_Cin, max_Cout, ppp > 0 ? ppp : kDefaultPairsPerPoint), flags};
 }
 
 bool cache_cfg_ok(const conv3p_cache_config *cfg)
@@ -634,7 +793,8 @@ size_t conv3p_workspace_bytes(int pass, int elem_bytes, int B, int N, int Cin, i
     const int32_t one[3] = {1, 1, 1};
     if (check(d, one, 1.0, pass != CONV3P_PASS_NEIGHBOR_COUNT) != CONV3P_OK) return 0;
     const int ppp = pass == CONV3P_PASS_NEIGHBOR_COUNT ? 0 : kDefaultPairsPerPoint;
-    const size_t scratch = pass == CONV3P_PASS_BACKWARD ? backward_scratch_bytes(d, elem_bytes) : 0;
+    const size_t scratch = pass == CONV3P_PASS_BACKWARD ? backward_scratch_bytes(d, elem_bytes)
+                           : pass == CONV3P_PASS_FORWARD ? forward_scratch_bytes(d, elem_bytes) : 0;
     const size_t b = layout_bytes(elem_bytes, B, N, d.ntap, 1, ppp, scratch);
     return b ? b : kAlign;
 }
@@ -644,7 +804,7 @@ size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_confi
     if ((elem_bytes != 4 && elem_bytes != 8) || B < 0 || N < 0 || !cache_cfg_ok(cfg)) return 0;
     const int ppp = cfg->pairs_per_point > 0 ? cfg->pairs_per_point : kDefaultPairsPerPoint;
     return layout_bytes(elem_bytes, B, N, cfg->max_taps, cfg->slots, ppp,
-                        cache_scratch_bytes(elem_bytes, B, N, cfg->max_taps, cfg->max_Cin, cfg->max_Cout));
+                        cache_scratch_bytes(elem_bytes, B, N, cfg->max_taps, cfg->max_Cin, cfg->max_Cout, ppp));
 }
 
 int conv3p_cache_forget(void *cache)

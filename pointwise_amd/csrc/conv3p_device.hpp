@@ -42,6 +42,9 @@ constexpr int kTile = 64;         // points per tile == wavefront size on gfx950
 constexpr int kCntStride = 65;    // LDS row stride of the [tap][lane] tables (bank-conflict-free)
 constexpr int kWavesPerBlock = 4;
 
+// LDS carve helper (all offsets multiples of 16 B; one extern array per kernel)
+__device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
 // One staged point: 16 B for float, 32 B for double.
 template <typename T> struct PointRec;
 template <> struct __attribute__((aligned(16))) PointRec<float> {

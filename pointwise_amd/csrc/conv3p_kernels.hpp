@@ -9,6 +9,7 @@
 #pragma once
 
 #include "conv3p_device.hpp"
+#include "conv3p_deep.hpp"
 
 #ifndef CONV3P_ABLATE
 #define CONV3P_ABLATE 0   // developer ablation switch (tools/ablate.sh); 0 in every shipped build
@@ -253,8 +254,6 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
     }
 }
 
-// LDS carve helpers (all offsets multiples of 16 B; one extern array per kernel).
-__device__ __forceinline__ size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // ---------------------------------------------------------------------------------
 // search: the geometry of the op, done ONCE per (points, filter extents, stride, voxel).
@@ -548,7 +547,7 @@ __global__ __launch_bounds__(256) void forward_kernel(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
-    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output)
+    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -574,6 +573,7 @@ __global__ __launch_bounds__(256) void forward_kernel(
         for (size_t e = threadIdx.x; e < nw; e += blockDim.x) w_lds[e] = filter[e];
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;   // uniform
+    if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
     const PointRec<T> me = cloud_pts[(size_t)qt * kTile + lane];
     if (wave == 0) qorig[lane] = me.idx;
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const T *__restrict__ grad_out, const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st,
     int N, int ntiles, int ngroups, int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ grad_input,
-    T *__restrict__ partials)
+    T *__restrict__ partials, const uint8_t *__restrict__ only_flagged)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -746,7 +746,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
     }
 
     int b, qt;
-    const bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
+    bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
+    if (live && only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) live = false;   // deep path did it
     const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
     PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
     if (!live) me.idx = -1;

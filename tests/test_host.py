@@ -64,7 +64,7 @@ def test_cache_bytes():
     one = lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(1, 27, 0, 9, 9)))
     four = lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(cfg))
     assert 0 < one < four and four % 256 == 0
-    assert four >= 4 * 32 * 2048 * (27 * 4 + 128 * 16)              # populations + pair records per slot
+    assert four >= 4 * 32 * 2048 * (27 * 4 + 256 * 16)              # populations + pair records per slot
     assert lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(0, 27, 0, 9, 9))) == 0
     assert lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(4, 5000, 0, 9, 9))) == 0
     assert lib.conv3p_cache_bytes(2, 32, 2048, ctypes.byref(cfg)) == 0
