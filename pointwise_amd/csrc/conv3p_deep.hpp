@@ -183,13 +183,33 @@ __global__ __launch_bounds__(256) void deep_gemm_kernel(const PointRec<float> *_
             float av[KPL];
 #pragma unroll
             for (int u = 0; u < KPL; ++u) av[u] = 0.0f;
-            for (uint32_t p = r0; p < r1; ++p) {
-                const PairEntry en = seg[qrel[q] + order[qbase[q] + p]];
-                const float w = BWD ? en.rcp_bwd : en.rcp_fwd;
-                const float *row = src_cloud + (size_t)en.cand * KDIM;
+            for (uint32_t p0 = r0; p0 < r1; p0 += 64) {
+                // lanes fetch (neighbour, weight) of up to 64 records in parallel: one latency, not one per record
+                uint32_t mcand = 0;
+                float mw = 0.0f;
+                if (p0 + lane < r1) {
+                    const PairEntry en = seg[qrel[q] + order[qbase[q] + p0 + lane]];
+                    mcand = en.cand;
+                    mw = BWD ? en.rcp_bwd : en.rcp_fwd;
+                }
+                const int nrec = (int)min(64u, r1 - p0);
+                for (int r = 0; r < nrec; r += 4) {
+                    // four independent row loads in flight
+                    float rv[4][KPL], wv[4];
 #pragma unroll
-                for (int u = 0; u < KPL; ++u)
-                    if (lane + 64 * u < KDIM) av[u] = __builtin_fmaf(row[lane + 64 * u], w, av[u]);
+                    for (int t = 0; t < 4; ++t) {
+                        const int rr = r + t < nrec ? r + t : r;
+                        const uint32_t cand = __shfl(mcand, rr);
+                        wv[t] = r + t < nrec ? __shfl(mw, rr) : 0.0f;
+                        const float *row = src_cloud + (size_t)cand * KDIM;
+#pragma unroll
+                        for (int u = 0; u < KPL; ++u) rv[t][u] = lane + 64 * u < KDIM ? row[lane + 64 * u] : 0.0f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int u = 0; u < KPL; ++u) av[u] = __builtin_fmaf(rv[t][u], wv[t], av[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < KPL; ++u)
@@ -257,6 +277,8 @@ __global__ __launch_bounds__(256) void deep_dw_kernel(const PointRec<float> *__r
     float *X = reinterpret_cast<float *>(smem);
     float *G = reinterpret_cast<float *>(smem + align16((size_t)64 * LDX * 4));
     __shared__ int32_t qorig[64];
+    __shared__ uint32_t mcand[256], mq[256];
+    __shared__ float mrcp[256];
 
     const int f = blockIdx.x, slice = blockIdx.y, chunk = blockIdx.z;
     const int n0 = slice * 64;
@@ -291,10 +313,22 @@ __global__ __launch_bounds__(256) void deep_dw_kernel(const PointRec<float> *__r
         }
         // G[q][0..64) += dY[cand][n0..n0+64) / count   (records of a centre are consecutive; wave = q & 3 owns it)
         const float *dy_cloud = grad_out + (size_t)b * N * COUT;
-        for (uint32_t e = e0; e < e1; ++e) {
-            const PairEntry en = seg[ord[e]];
-            const uint32_t q = code_q(en.code);
-            if ((int)(q & 3) == wave) G[q * 65 + lane] += dy_cloud[(size_t)en.cand * COUT + n0 + lane] * en.rcp_bwd;
+        for (uint32_t eb = e0; eb < e1; eb += 256) {
+            // 256 threads fetch the metadata of up to 256 records in parallel, then every wave walks them
+            __syncthreads();
+            if (eb + threadIdx.x < e1) {
+                const PairEntry en = seg[ord[eb + threadIdx.x]];
+                mcand[threadIdx.x] = en.cand;
+                mq[threadIdx.x] = code_q(en.code);
+                mrcp[threadIdx.x] = en.rcp_bwd;
+            }
+            __syncthreads();
+            const int nrec = (int)min(256u, e1 - eb);
+            for (int r = 0; r < nrec; ++r) {
+                const uint32_t q = mq[r];
+                if ((int)(q & 3) == wave)
+                    G[q * 65 + lane] += dy_cloud[(size_t)mcand[r] * COUT + n0 + lane] * mrcp[r];
+            }
         }
         __syncthreads();
         // X^T [CIN x 64] . G [64 x 64]
