@@ -357,3 +357,53 @@ def test_stack_with_cache_hints_over_changing_batches(dev):
         for u, v in zip(a1, a2):
             assert torch.equal(u, v)
         assert torch.equal(dx1, dx2) and torch.equal(f1, f2)
+
+
+# ------------------------------------------------------------------ deep-channel (matrix-core) path
+@pytest.mark.parametrize("ci,co", [(128, 256), (64, 128), (128, 128)])
+def test_deep_channel_path_matches_oracle(dev, ci, co):
+    """cfg5-shaped layers go through the factorised MFMA kernels (conv3p_deep.hpp); room-like data, several
+    tiles per cloud, both ops."""
+    B, N = 2, 700
+    P = synth.room_like(B, N, 950, extent=(1.0, 1.0, 1.5))
+    X = synth.features(B, N, ci, 951, points=P)
+    W = synth.filter_weights(3, 3, 3, ci, co, 952)
+    dY = synth.upstream_grad(B, N, co, 953)
+    s = (1, 1, 1)
+    ref = (oracle.neighbor_count(P, (3, 3, 3), s, VOX), oracle.forward(P, X, W, s, VOX, nthreads=8)) + \
+        oracle.backward(dY, P, X, W, s, VOX, nthreads=1)
+    check_against(ref, run_hip(dev, P, X, W, dY, s), np.float32)
+
+
+def test_deep_channel_path_is_used_and_reproducible(dev):
+    lib = _lib.load()
+    P, X, W, dY = make_case("room", 1, 256, 128, 256, seed=960)
+    lib.conv3p_profile_reset()
+    lib.conv3p_profile_enable(1)
+    a = _both(dev, None, P, X, W, dY, (1, 1, 1))
+    torch.cuda.synchronize()
+    lib.conv3p_profile_enable(0)
+    seen = {}
+    for k in range(lib.conv3p_profile_kinds()):
+        n = ctypes.c_uint64(0)
+        lib.conv3p_profile_read(k, ctypes.byref(n), None)
+        seen[lib.conv3p_profile_name(k).decode()] = n.value
+    lib.conv3p_profile_reset()
+    assert seen.get("deep_gemm_kernel", 0) == 2 and seen.get("deep_dw_kernel", 0) == 1, seen
+    b = _both(dev, None, P, X, W, dY, (1, 1, 1))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_pair_buffer_overflow_falls_back_correctly(dev):
+    """A cache configured with a tiny pair capacity overflows: the small-channel kernels search the tile
+    themselves, the deep path hands flagged tiles to the generic kernel.  Results must still be exact."""
+    for ci, co in ((9, 9), (32, 64)):
+        B, N = 2, 300
+        P, X, W, dY = make_case("room", B, N, ci, co, seed=970)
+        cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, pairs_per_point=4, max_cin=ci,
+                                 max_cout=co)
+        y, dx, dw = _both(dev, cache, P, X, W, dY, (1, 1, 1))
+        assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, (1, 1, 1), VOX)) <= 1e-5
+        dx_ref, dw_ref = oracle.backward(dY, P, X, W, (1, 1, 1), VOX)
+        assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
