@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--serial", action="store_true",
+                    help="developer: no side stream at all (clean per-kernel durations under rocprofv3)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not enqueue the next batch's neighbour search under the current batch's backward")
     args = ap.parse_args()
@@ -119,10 +121,10 @@ def main():
     tXs = [t.clone() for t in tPs]
     tP, tX = tPs[0], tXs[0]
     ups = [torch.from_numpy(u).to(dev) for u in ups_np]
-    st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234)
+    st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial)
     counter = [0]
 
-    prefetch = not args.no_prefetch
+    prefetch = not (args.no_prefetch or args.serial)
 
     def step():
         i = counter[0] % NBATCH

@@ -543,7 +543,9 @@ __global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__rest
 // A segment marked kSegOverflow makes the workgroup search its query tile itself.
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
-__global__ __launch_bounds__(256) void forward_kernel(
+// 4 waves per SIMD = 4 workgroups per CU: the 128 workgroups an XCD gets for cfg2 are resident in one round
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void forward_kernel(
+
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
@@ -577,15 +579,20 @@ __global__ __launch_bounds__(256) void forward_kernel(
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
     const PointRec<T> me = cloud_pts[(size_t)qt * kTile + lane];
     if (wave == 0) qorig[lane] = me.idx;
+    const size_t tile_id = (size_t)b * ntiles + qt;
+    bool overflow = false;
+    for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
     __syncthreads();
-    // own populations -> LDS [tap][centre]
-    for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
-        const int orig = qorig[qq];
-        if (orig < 0) continue;
-        const int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
-        for (int f = lane; f < st.ntap; f += 64) cnt[f * kCntStride + qq] = (uint32_t)row[f];
+    if (!kSmall || overflow) {
+        // own populations -> LDS [tap][centre] (the dense small path carries 1/count in the pair records)
+        for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
+            const int orig = qorig[qq];
+            if (orig < 0) continue;
+            const int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
+            for (int f = lane; f < st.ntap; f += 64) cnt[f * kCntStride + qq] = (uint32_t)row[f];
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     const T *in_cloud = input + (size_t)b * N * cin;
     T *out_cloud = output + (size_t)b * N * cout;
@@ -619,9 +626,6 @@ __global__ __launch_bounds__(256) void forward_kernel(
         }
     };
 
-    const size_t tile_id = (size_t)b * ntiles + qt;
-    bool overflow = false;
-    for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
     if (!overflow) {
         for (int g = 0; g < ngroups; ++g) {
             if constexpr (kSmall) {
@@ -815,24 +819,23 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     // lower sub-lane goes first (fixed order), the other retries -> race-free, reproducible.
                     const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                     const PairEntry *pe = pairs + sg.x;
+                    // software pipeline: record two steps ahead, dY row one step ahead
+                    auto live_rec = [&](const PairEntry &r, uint32_t i) { return i < sg.y && r.rcp_bwd > 0.0f; };
                     PairEntry cur = pe[(uint32_t)sub < sg.y ? sub : 0];
+                    PairEntry nxt = pe[(uint32_t)sub + 4 < sg.y ? sub + 4 : 0];
+                    T val[COUT];
+                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(live_rec(cur, sub) ? cur.cand : 0) * COUT, val);
                     T ablate_sink = (T)0;
                     for (uint32_t i = sub; __any(i < sg.y); i += 4) {
-                        const uint32_t nx = i + 4;
-                        const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
+                        const PairEntry nn = pe[i + 8 < sg.y ? i + 8 : 0];
+                        T nval[COUT];
+                        RowLoader<T, COUT>::load(dy_cloud + (size_t)(live_rec(nxt, i + 4) ? nxt.cand : 0) * COUT, nval);
                         // rcp_bwd == 0: false positive, hole, or empty tap -> contributes nothing
-                        bool pending = i < sg.y && cur.rcp_bwd > 0.0f;
+                        bool pending = live_rec(cur, i);
                         const uint32_t fb = code_bwd(cur.code);
-                        T val[COUT];
                         if (pending) {
-                            if (CONV3P_ABLATE & 128) {
 #pragma unroll
-                                for (int c = 0; c < COUT; ++c) val[c] = (T)cur.rcp_bwd;
-                            } else {
-                                RowLoader<T, COUT>::load(dy_cloud + (size_t)cur.cand * COUT, val);
-#pragma unroll
-                                for (int c = 0; c < COUT; ++c) val[c] *= (T)cur.rcp_bwd;
-                            }
+                            for (int c = 0; c < COUT; ++c) val[c] *= (T)cur.rcp_bwd;
                         }
                         if (CONV3P_ABLATE & 256) {
                             if (pending) {
@@ -881,6 +884,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
                             for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += val[c];
                         }
                         cur = nxt;
+                        nxt = nn;
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) val[c] = nval[c];
                     }
                     if (CONV3P_ABLATE & 256) G[cq] += ablate_sink;
                 } else {
