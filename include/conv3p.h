@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CONV3P_ABI_VERSION 1
+#define CONV3P_ABI_VERSION 2
 
 /* status codes */
 #define CONV3P_OK 0
@@ -189,6 +189,37 @@ int conv3p_selu_grad_add_f32(const float *y, const float *dy_a, const float *dy_
                              size_t n, void *stream);
 int conv3p_selu_grad_add_f64(const double *y, const double *dy_a, const double *dy_b, double *dx,
                              size_t n, void *stream);
+
+/* The models' layer: conv3p followed by SELU (pointcnn2_acsd.py:48-67:
+ *   net = selu(conv3p(points, net, W, stride, voxel))), with the activation fused into the op's kernels.
+ * conv3p_layer_forward:   output = selu(Conv3p(points, input, filter, stride, voxel)).
+ * conv3p_layer_backward:  for a layer whose `input` is itself the OUTPUT of a SELU (every layer but the
+ *   first): grad_filter as Conv3pGrad; grad_input = (dX + grad_addend) * selu'(input), i.e. the gradient
+ *   w.r.t. the ARGUMENT of the SELU that produced `input`, where dX is Conv3pGrad's grad_input and
+ *   grad_addend (may be NULL) is the gradient arriving at `input` from its other consumer (the feature
+ *   concat, pointcnn2_acsd.py:66).  `grad_out` is the gradient w.r.t. this layer's conv3p output (already
+ *   through this layer's own SELU).  Results equal the unfused sequence conv3p_*_cached + conv3p_selu* up
+ *   to the rounding of one multiply. */
+int conv3p_layer_forward_cached_f32(const float *points, const float *input, const float *filter,
+                                    const int32_t *stride_xyz, float voxel_size, int B, int N, int Cin,
+                                    int Cout, int fz, int fy, int fx, float *output, void *cache,
+                                    size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+int conv3p_layer_forward_cached_f64(const double *points, const double *input, const double *filter,
+                                    const int32_t *stride_xyz, double voxel_size, int B, int N, int Cin,
+                                    int Cout, int fz, int fy, int fx, double *output, void *cache,
+                                    size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+int conv3p_layer_backward_cached_f32(const float *grad_out, const float *points, const float *input,
+                                     const float *filter, const int32_t *stride_xyz, float voxel_size,
+                                     int B, int N, int Cin, int Cout, int fz, int fy, int fx,
+                                     const float *grad_addend, float *grad_input, float *grad_filter,
+                                     void *cache, size_t cache_bytes, const conv3p_cache_config *cfg,
+                                     void *stream);
+int conv3p_layer_backward_cached_f64(const double *grad_out, const double *points, const double *input,
+                                     const double *filter, const int32_t *stride_xyz, double voxel_size,
+                                     int B, int N, int Cin, int Cout, int fz, int fy, int fx,
+                                     const double *grad_addend, double *grad_input, double *grad_filter,
+                                     void *cache, size_t cache_bytes, const conv3p_cache_config *cfg,
+                                     void *stream);
 
 /* Kernel-level timing with HIP events recorded on the caller's stream (bench.py uses it
  * to derive the roofline of the dominant kernel).  Off by default; when enabled every

@@ -5,7 +5,7 @@ conv3p_op (host mirror of the reference's operator interface), stack (the models
 distributed (batch sharding + RCCL all-reduce of the weight gradients), synth (synthetic clouds).
 """
 from .conv3p_op import (Conv3pFunction, Conv3pInvalidArgument, Conv3pRuntimeError, conv3p, conv3p_autograd,
-                        conv3p_grad, neighbor_count, selu, selu_grad)
+                        conv3p_grad, conv3p_layer, conv3p_layer_grad, neighbor_count, selu, selu_grad)
 
-__all__ = ["conv3p", "conv3p_grad", "conv3p_autograd", "Conv3pFunction", "neighbor_count", "selu", "selu_grad",
+__all__ = ["conv3p", "conv3p_grad", "conv3p_layer", "conv3p_layer_grad", "conv3p_autograd", "Conv3pFunction", "neighbor_count", "selu", "selu_grad",
            "Conv3pInvalidArgument", "Conv3pRuntimeError"]

@@ -20,6 +20,7 @@ PASS_FORWARD = 0
 PASS_BACKWARD = 1
 PASS_NEIGHBOR_COUNT = 2
 CACHE_POINTS_UNCHANGED = 1
+ABI_VERSION = 2                # CONV3P_ABI_VERSION of include/conv3p.h
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -32,6 +33,9 @@ def _sig(real):
         "backward": (_i, [_vp, _vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
         "forward_cached": (_i, [_vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
         "backward_cached": (_i, [_vp, _vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+        "layer_forward_cached": (_i, [_vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+        "layer_backward_cached": (_i, [_vp, _vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
+                                       _vp, _vp]),
         "cache_prepare": (_i, [_vp, _vp, real, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
         "neighbor_count": (_i, [_vp, _vp, real, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
         "selu": (_i, [_vp, _vp, _sz, _vp]),
@@ -86,7 +90,7 @@ def load():
             raise Conv3pLibraryError("libconv3p_hip.so does not export %s" % name)
         fn.restype = res
         fn.argtypes = args
-    if lib.conv3p_abi_version() != 1:
+    if lib.conv3p_abi_version() != ABI_VERSION:
         raise Conv3pLibraryError("libconv3p_hip.so ABI version mismatch")
     _LIB = lib
     return lib

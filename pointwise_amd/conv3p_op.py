@@ -137,7 +137,7 @@ def _call(fn, *args):
     raise Conv3pRuntimeError(msg)
 
 
-def conv3p(points, input, filter, stride, voxel_size, cache=None, points_unchanged=False):
+def conv3p(points, input, filter, stride, voxel_size, cache=None, points_unchanged=False, _fused_selu=False):
     """Conv3p forward.  points (B,N,3), input (B,N,Cin), filter (fz,fy,fx,Cin,Cout), stride [sx,sy,sz]
     (int32[3]), voxel_size T[1] -> output (B,N,Cout).  Mirrors conv3p_module.conv3p
     (/root/reference/pointcnn2_acsd.py:12-13).  cache (optional, not in the reference): a NeighborCache."""
@@ -154,11 +154,14 @@ def conv3p(points, input, filter, stride, voxel_size, cache=None, points_unchang
     with torch.cuda.device(dev):
         if cache is not None and cache.fits(B, N, points.dtype, dev, fz * fy * fx, Cin, Cout):
             stream = torch.cuda.current_stream(dev)
-            _call(getattr(lib, "conv3p_forward_cached_" + sfx), points.data_ptr(), input.data_ptr(),
+            _call(getattr(lib, ("conv3p_layer_forward_cached_" if _fused_selu else "conv3p_forward_cached_") + sfx),
+                  points.data_ptr(), input.data_ptr(),
                   filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx,
                   out.data_ptr(), cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(points_unchanged),
                   stream.cuda_stream)
         else:
+            if _fused_selu:
+                raise Conv3pInvalidArgument("conv3p_layer needs a NeighborCache that fits these clouds")
             need = lib.conv3p_workspace_bytes(_lib.PASS_FORWARD, esz, B, N, Cin, Cout, fz, fy, fx)
             ws, stream = _workspace(dev, need)
             _call(getattr(lib, "conv3p_forward_" + sfx), points.data_ptr(), input.data_ptr(), filter.data_ptr(),
@@ -168,7 +171,7 @@ def conv3p(points, input, filter, stride, voxel_size, cache=None, points_unchang
 
 
 def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_filter_out=None, cache=None,
-                points_unchanged=False):
+                points_unchanged=False, _fused_selu=False, _grad_addend=None):
     """Conv3pGrad -> (grad_input, grad_filter).  Mirrors conv3p_module.conv3p_grad
     (/root/reference/pointcnn2_acsd.py:30; schema register_op.cpp:63-75).
     grad_filter_out (optional, not in the reference): a contiguous tensor shaped like filter to write
@@ -197,17 +200,49 @@ def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_
     with torch.cuda.device(dev):
         if cache is not None and cache.fits(B, N, points.dtype, dev, fz * fy * fx, Cin, Cout):
             stream = torch.cuda.current_stream(dev)
-            _call(getattr(lib, "conv3p_backward_cached_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
-                  input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
-                  Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
-                  cache.cfg_ptr(points_unchanged), stream.cuda_stream)
+            if _fused_selu:
+                add = None
+                if _grad_addend is not None:
+                    add = _grad_addend
+                    if add.shape != input.shape or add.dtype != input.dtype or add.device != dev:
+                        raise Conv3pInvalidArgument("grad_addend must be a tensor like input")
+                    add = add.contiguous()
+                _call(getattr(lib, "conv3p_layer_backward_cached_" + sfx), grad_from_next.data_ptr(),
+                      points.data_ptr(), input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p),
+                      creal(vox), B, N, Cin, Cout, fz, fy, fx, add.data_ptr() if add is not None else None,
+                      dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
+                      cache.cfg_ptr(points_unchanged), stream.cuda_stream)
+            else:
+                _call(getattr(lib, "conv3p_backward_cached_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
+                      input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
+                      Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
+                      cache.cfg_ptr(points_unchanged), stream.cuda_stream)
         else:
+            if _fused_selu:
+                raise Conv3pInvalidArgument("conv3p_layer_grad needs a NeighborCache that fits these clouds")
             need = lib.conv3p_workspace_bytes(_lib.PASS_BACKWARD, esz, B, N, Cin, Cout, fz, fy, fx)
             ws, stream = _workspace(dev, need)
             _call(getattr(lib, "conv3p_backward_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
                   input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
                   Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
     return dx, dw
+
+
+def conv3p_layer(points, input, filter, stride, voxel_size, cache, points_unchanged=False):
+    """selu(conv3p(points, input, filter, stride, voxel_size)): the models' layer
+    (/root/reference/pointcnn2_acsd.py:48-49), SELU fused into the op (conv3p_layer_forward_cached_*)."""
+    return conv3p(points, input, filter, stride, voxel_size, cache=cache, points_unchanged=points_unchanged,
+                  _fused_selu=True)
+
+
+def conv3p_layer_grad(grad_from_next, points, input, filter, stride, voxel_size, cache, grad_addend=None,
+                      grad_filter_out=None, points_unchanged=False):
+    """Backward of a layer whose `input` is a SELU output (conv3p_layer_backward_cached_*):
+    returns ((dX + grad_addend) * selu'(input), grad_filter) where (dX, grad_filter) = conv3p_grad(...), i.e.
+    the gradient w.r.t. the argument of the SELU that produced `input`; grad_addend is the gradient `input`
+    receives from its other consumer (the concat of pointcnn2_acsd.py:66)."""
+    return conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_filter_out=grad_filter_out,
+                       cache=cache, points_unchanged=points_unchanged, _fused_selu=True, _grad_addend=grad_addend)
 
 
 def cache_prepare(points, filter_zyx, stride, voxel_size, cache, points_unchanged=False, stream=None):

@@ -277,6 +277,10 @@ template <typename T> struct Call {
     bool evicted_hinted = false;   // slot re-assigned to a new stencil while prep is skipped: reset its allocators
     bool skip_prep = false;     // caller promised unchanged points
     bool skip_search = false;   // ... and this slot's lists were already enqueued for them
+    // conv3p_layer_*: SELU fused into the op (pointcnn2_acsd.py:48-49).  forward: output = selu(conv);
+    // backward: grad_input = (dX + addend) * selu'(input)
+    bool act = false;
+    const T *addend = nullptr;
 };
 
 template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned long long tag, uint32_t epoch, int force)
@@ -370,7 +374,7 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, d.Cin, d.Cout,
-                       bm, output, only_flagged);
+                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0);
     return hip_ok();
 }
 
@@ -394,7 +398,8 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
-                       d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged);
+                       d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
+                       (CI > 0 && c.act) ? 1 : 0, c.addend);
     return hip_ok();
 }
 
@@ -607,9 +612,13 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     return CONV3P_OK;
 }
 
+template <typename T> int selu_impl(const T *x, T *y, size_t n, void *stream);
+template <typename T> int selu_grad_impl(const T *y, const T *dy, const T *dy_b, T *dx, size_t n, void *stream);
+
 template <typename T>
 int forward_impl(const T *points, const T *input, const T *filter, const int32_t *stride, T voxel, int B,
-                 int N, int Cin, int Cout, int fz, int fy, int fx, T *output, const Where &wh, void *stream)
+                 int N, int Cin, int Cout, int fz, int fy, int fx, T *output, const Where &wh, void *stream,
+                 bool act = false)
 {
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     TRY(check(d, stride, (double)voxel, true));
@@ -617,8 +626,9 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     const size_t out_elems = (size_t)B * N * Cout;
     if (out_elems == 0) return CONV3P_OK;
     if (!points || !output || (Cin > 0 && (!input || !filter))) return CONV3P_ERR_INVALID_ARGUMENT;
-    if (Cin == 0) return zero_async(output, out_elems * sizeof(T), s);   // empty contraction
+    if (Cin == 0) return zero_async(output, out_elems * sizeof(T), s);   // empty contraction; selu(0) == 0
     Call<T> c;
+    c.act = act;
     TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T)), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
@@ -634,14 +644,15 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \
         int rc = deep_forward<ci, co>(c, input, filter, output);                                     \
-        if (rc != CONV3P_ERR_UNSUPPORTED) return rc;                                                 \
+        if (rc != CONV3P_ERR_UNSUPPORTED) return rc != CONV3P_OK || !act ? rc : selu_impl<T>(output, output, out_elems, stream); \
     }
             CONV3P_DEEP_SHAPES(X)
 #undef X
         }
     }
     TRY(zero_async(output, out_elems * sizeof(T), s));                   // .cpp:451
-    return launch_forward<T, 0, 0>(c, input, filter, output);
+    TRY((launch_forward<T, 0, 0>(c, input, filter, output)));
+    return act ? selu_impl<T>(output, output, out_elems, stream) : CONV3P_OK;   // paths without a fused epilogue
 }
 
 // geometry only: what a later forward / backward with the same points + stencil will find ready
@@ -662,7 +673,8 @@ int prepare_impl(const T *points, const int32_t *stride, T voxel, int B, int N, 
 template <typename T>
 int backward_impl(const T *grad_out, const T *points, const T *input, const T *filter,
                   const int32_t *stride, T voxel, int B, int N, int Cin, int Cout, int fz, int fy, int fx,
-                  T *grad_input, T *grad_filter, const Where &wh, void *stream)
+                  T *grad_input, T *grad_filter, const Where &wh, void *stream, bool act = false,
+                  const T *addend = nullptr)
 {
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     TRY(check(d, stride, (double)voxel, true));
@@ -672,10 +684,17 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     if ((dx_elems && !grad_input) || (nw && !grad_filter)) return CONV3P_ERR_INVALID_ARGUMENT;
     if (dx_elems == 0 || Cout == 0) {                                    // nothing to accumulate
         TRY(zero_async(grad_input, dx_elems * sizeof(T), s));            // .cpp:580
-        return zero_async(grad_filter, nw * sizeof(T), s);               // .cpp:590
+        TRY(zero_async(grad_filter, nw * sizeof(T), s));                 // .cpp:590
+        if (act && dx_elems && addend) {
+            if (!input) return CONV3P_ERR_INVALID_ARGUMENT;
+            return selu_grad_impl<T>(input, addend, nullptr, grad_input, dx_elems, stream);
+        }
+        return CONV3P_OK;
     }
     if (!points || !input || !filter || !grad_out) return CONV3P_ERR_INVALID_ARGUMENT;
     Call<T> c;
+    c.act = act;
+    c.addend = addend;
     TRY(begin_call<T>(c, d, stride, voxel, backward_scratch_bytes(d, (int)sizeof(T)), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
@@ -690,7 +709,9 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \
         int drc = deep_backward<ci, co>(c, grad_out, input, filter, grad_input, grad_filter);        \
-        if (drc != CONV3P_ERR_UNSUPPORTED) return drc;                                               \
+        if (drc != CONV3P_ERR_UNSUPPORTED)                                                           \
+            return drc != CONV3P_OK || !act ? drc                                                    \
+                       : selu_grad_impl<T>(input, grad_input, addend, grad_input, dx_elems, stream); \
     }
             CONV3P_DEEP_SHAPES(X)
 #undef X
@@ -708,7 +729,10 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
         hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nw + 63) / 64)), dim3(1024), 0, s,
                            c.L.partials, nslots, nw, grad_filter);
     }
-    return hip_ok();
+    TRY(hip_ok());
+    if (act && nslots == 1)   // generic path has no fused epilogue
+        return selu_grad_impl<T>(input, grad_input, addend, grad_input, dx_elems, stream);
+    return CONV3P_OK;
 }
 
 template <typename T>
@@ -864,6 +888,31 @@ int conv3p_backward_cached_f64(BWD_ARGS(double), CACHE_ARGS)
 {
     if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
     return backward_impl<double>(BWD_PASS, CACHE_WHERE(8), stream);
+}
+
+int conv3p_layer_forward_cached_f32(FWD_ARGS(float), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return forward_impl<float>(FWD_PASS, CACHE_WHERE(4), stream, true);
+}
+int conv3p_layer_forward_cached_f64(FWD_ARGS(double), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return forward_impl<double>(FWD_PASS, CACHE_WHERE(8), stream, true);
+}
+#define LAYER_BWD_ARGS(T)                                                                                      \
+    const T *grad_out, const T *points, const T *input, const T *filter, const int32_t *stride_xyz,            \
+        T voxel_size, int B, int N, int Cin, int Cout, int fz, int fy, int fx, const T *grad_addend,           \
+        T *grad_input, T *grad_filter
+int conv3p_layer_backward_cached_f32(LAYER_BWD_ARGS(float), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return backward_impl<float>(BWD_PASS, CACHE_WHERE(4), stream, true, grad_addend);
+}
+int conv3p_layer_backward_cached_f64(LAYER_BWD_ARGS(double), CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return backward_impl<double>(BWD_PASS, CACHE_WHERE(8), stream, true, grad_addend);
 }
 
 int conv3p_cache_prepare_f32(const float *points, const int32_t *stride_xyz, float voxel_size, int B, int N,

@@ -51,6 +51,23 @@ __device__ __forceinline__ bool slot_valid(const CacheCtl &cc, int b)
     return !cc.force && cc.built_version[b] == cc.version[b] && cc.built_tag[b] == cc.tag;
 }
 
+// SELU (selu.py:22-26): scale * (x >= 0 ? x : alpha * (exp(x) - 1)); its derivative expressed through the
+// OUTPUT y (what TensorFlow's SeluGrad takes): y >= 0 ? scale : y + scale * alpha.
+template <typename T> struct SeluConst {
+    static constexpr double alpha = 1.6732632423543772848170429916717;
+    static constexpr double scale = 1.0507009873554804934193349852946;
+};
+__device__ __forceinline__ float expm1_t(float v) { return expm1f(v); }
+__device__ __forceinline__ double expm1_t(double v) { return expm1(v); }
+template <typename T> __device__ __forceinline__ T selu_value(T v)
+{
+    return (T)SeluConst<T>::scale * (v >= (T)0 ? v : (T)SeluConst<T>::alpha * expm1_t(v));
+}
+template <typename T> __device__ __forceinline__ T selu_slope(T y)
+{
+    return y >= (T)0 ? (T)SeluConst<T>::scale : y + (T)(SeluConst<T>::scale * SeluConst<T>::alpha);
+}
+
 // ---------------------------------------------------------------------------------
 // prep: one wavefront per tile.  Identity order (tile t = points [64t, 64t+64)).
 // Padding lanes of the last tile get +inf coordinates (rejected by every finite box)
@@ -549,7 +566,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
-    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged)
+    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged,
+    int act)   // act != 0 (small path only): store selu(out), the models' layer (pointcnn2_acsd.py:48-49)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -674,7 +692,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                 T v = acc[c];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (sub == 0 && orig >= 0) out_cloud[(size_t)orig * COUT + c] = v;
+                if (sub == 0 && orig >= 0) out_cloud[(size_t)orig * COUT + c] = act ? selu_value(v) : v;
             }
         } else {
             // overflow path ran lane = centre in every wave: fixed-order sum of the per-wave partial rows
@@ -686,7 +704,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
                 T sum = red[((size_t)0 * COUT + c) * 64 + lane];
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * COUT + c) * 64 + lane];
-                if (me.idx >= 0) out_cloud[(size_t)me.idx * COUT + c] = sum;
+                if (me.idx >= 0) out_cloud[(size_t)me.idx * COUT + c] = act ? selu_value(sum) : sum;
             }
         }
     }
@@ -715,7 +733,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const T *__restrict__ grad_out, const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st,
     int N, int ntiles, int ngroups, int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ grad_input,
-    T *__restrict__ partials, const uint8_t *__restrict__ only_flagged)
+    T *__restrict__ partials, const uint8_t *__restrict__ only_flagged,
+    int act, const T *__restrict__ addend)   // act != 0 (small path only): `input` is a SELU output; store
+                                             // (dX + addend) * selu'(input), the gradient w.r.t. that SELU's argument
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -924,10 +944,15 @@ __global__ __launch_bounds__(256) void backward_kernel(
 #pragma unroll
             for (int k = 0; k < CIN; ++k) acc[k] = (T)0;
             const T *grow = G + (size_t)row * kCntStride;
-            for (int j = 0; j < 64; ++j) {
-                const T g = grow[j];
+#pragma unroll 1
+            for (int j0 = 0; j0 < 64; j0 += 8) {
+                T g[8];
 #pragma unroll
-                for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g, xt[j * CIN + k], acc[k]);
+                for (int u = 0; u < 8; ++u) g[u] = grow[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g[u], xt[(j0 + u) * CIN + k], acc[k]);
             }
             const int f = row / COUT, c = row - f * COUT;
 #pragma unroll
@@ -937,12 +962,29 @@ __global__ __launch_bounds__(256) void backward_kernel(
         T dx[CIN];
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
-        for (int row = wave; row < ((CONV3P_ABLATE & 4) ? 0 : nrows); row += kWavesPerBlock) {
-            const T g = G[(size_t)row * kCntStride + lane];
-            if (!__any(g != (T)0)) continue;
-            const T *wr = wt + (size_t)row * CIN;
+        // rows are taken 4 at a time per wave so that the LDS reads of a step are independent (the loop is
+        // latency-bound at 2 waves per SIMD); summation order stays fixed: ascending row within a wave
+        {
+            constexpr int kU = 4;
+            const int nr = (CONV3P_ABLATE & 4) ? 0 : nrows;
+            int row = wave;
+            for (; row + (kU - 1) * kWavesPerBlock < nr; row += kU * kWavesPerBlock) {
+                T g[kU];
 #pragma unroll
-            for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
+                for (int u = 0; u < kU; ++u) g[u] = G[(size_t)(row + u * kWavesPerBlock) * kCntStride + lane];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const T *wr = wt + (size_t)(row + u * kWavesPerBlock) * CIN;
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g[u], wr[k], dx[k]);
+                }
+            }
+            for (; row < nr; row += kWavesPerBlock) {
+                const T g = G[(size_t)row * kCntStride + lane];
+                const T *wr = wt + (size_t)row * CIN;
+#pragma unroll
+                for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
+            }
         }
         __syncthreads();   // red aliases wt / xt: every wave is done reading them
 #pragma unroll
@@ -954,7 +996,11 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 T sum = red[((size_t)0 * CIN + k) * 64 + lane];
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
-                if (me.idx >= 0) grad_input[((size_t)b * N + me.idx) * CIN + k] = sum;
+                if (me.idx >= 0) {
+                    const size_t o = ((size_t)b * N + me.idx) * CIN + k;
+                    if (act) sum = (addend ? sum + addend[o] : sum) * selu_slope(input[o]);
+                    grad_input[o] = sum;
+                }
             }
     }
 }
@@ -991,29 +1037,19 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const T *__restri
     }
 }
 
-// SELU (selu.py:22-26): scale * (x >= 0 ? x : alpha * (exp(x) - 1)).
-template <typename T> struct SeluConst {
-    static constexpr double alpha = 1.6732632423543772848170429916717;
-    static constexpr double scale = 1.0507009873554804934193349852946;
-};
 template <typename T>
-__global__ __launch_bounds__(256) void selu_kernel(const T *__restrict__ x, T *__restrict__ y, size_t n)
+__global__ __launch_bounds__(256) void selu_kernel(const T *x, T *y, size_t n)   // y may alias x
 {
-    const T alpha = (T)SeluConst<T>::alpha, scale = (T)SeluConst<T>::scale;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const T v = x[i];
-        y[i] = scale * (v >= (T)0 ? v : alpha * (T)expm1((double)v));
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = selu_value(x[i]);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void selu_grad_kernel(const T *__restrict__ y, const T *__restrict__ dy,
-                                                        const T *__restrict__ dy_b, T *__restrict__ dx, size_t n)
+__global__ __launch_bounds__(256) void selu_grad_kernel(const T *y, const T *dy, const T *dy_b, T *dx,
+                                                        size_t n)   // dx may alias dy
 {
-    const T alpha = (T)SeluConst<T>::alpha, scale = (T)SeluConst<T>::scale;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const T v = y[i];
         const T g = dy_b ? dy[i] + dy_b[i] : dy[i];
-        dx[i] = g * (v >= (T)0 ? scale : v + scale * alpha);
+        dx[i] = g * selu_slope(y[i]);
     }
 }
 

@@ -25,11 +25,13 @@ HIDDEN = 9
 
 class Conv3pStack:
     def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234,
-                 use_cache=True, overlap_search=True):
+                 use_cache=True, overlap_search=True, fuse_selu=True):
         """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers).
         use_cache: keep the geometry (sorted points, populations, neighbour lists) of each layer's stencil in
         a NeighborCache so that the search runs once per (points, stride) instead of once per op call."""
         self.use_cache = use_cache
+        # SELU fused into the op's epilogues (conv3p_layer_*): 1 activation launch per step instead of 8
+        self.fuse_selu = fuse_selu and use_cache
         # enqueue every layer's neighbour search on a second stream at the start of forward(): the search of
         # layer l+1 (VALU-bound) then runs while layer l accumulates (gather-latency-bound)
         self.overlap_search = overlap_search and use_cache
@@ -118,8 +120,11 @@ class Conv3pStack:
             _, _, s = self.layers[li]
             if events is not None:
                 main.wait_event(events[li])
-            x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL, cache=cache,
-                                  points_unchanged=li > 0 or events is not None))   # first call re-validates
+            hint = li > 0 or events is not None                      # the first call of a step re-validates
+            if self.fuse_selu:
+                x = op.conv3p_layer(points, x, self.filters[li], (s, s, s), VOXEL, cache, points_unchanged=hint)
+            else:
+                x = op.selu(op.conv3p(points, x, self.filters[li], (s, s, s), VOXEL, cache=cache, points_unchanged=hint))
             acts.append(x)
         concat = None
         if self.num_class is not None:
@@ -143,6 +148,18 @@ class Conv3pStack:
             ext = [dconcat[:, :, HIDDEN * i:HIDDEN * (i + 1)].contiguous() for i in range(4)]
         else:
             ext = list(upstream)
+        if self.fuse_selu:
+            # g = dL/d(conv output of layer li); each layer's backward emits the next g directly
+            g = op.selu_grad(acts[3], ext[3])
+            for li in (3, 2, 1):
+                _, _, s = self.layers[li]
+                g, _ = op.conv3p_layer_grad(g, points, acts[li - 1], self.filters[li], (s, s, s), VOXEL, cache,
+                                            grad_addend=ext[li - 1], grad_filter_out=self.grad_views[li],
+                                            points_unchanged=True)
+            _, _, s = self.layers[0]
+            carry, _ = op.conv3p_grad(g, points, features, self.filters[0], (s, s, s), VOXEL,
+                                      grad_filter_out=self.grad_views[0], cache=cache, points_unchanged=True)
+            return carry, self.fused_grad
         carry = None
         for li in (3, 2, 1, 0):
             _, _, s = self.layers[li]

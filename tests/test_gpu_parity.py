@@ -407,3 +407,50 @@ def test_pair_buffer_overflow_falls_back_correctly(dev):
         assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, (1, 1, 1), VOX)) <= 1e-5
         dx_ref, dw_ref = oracle.backward(dY, P, X, W, (1, 1, 1), VOX)
         assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
+
+
+# ------------------------------------------------------------------ fused conv3p + SELU layer ops
+@pytest.mark.parametrize("ci,co,dt", [(9, 9, np.float32), (3, 9, np.float32), (5, 7, np.float32), (32, 64, np.float32),
+                                      (5, 7, np.float64)])
+def test_layer_ops_equal_unfused_sequence(dev, ci, co, dt):
+    """conv3p_layer == selu(conv3p); conv3p_layer_grad == selu_grad(input, dX + addend), on every kernel family
+    (register path, generic path, deep path, fp64)."""
+    B, N = 2, 400
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=990, dtype=dt)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    tP, tW, tdY = t(P), t(W), t(dY)
+    tX = op.selu(t(X))                                  # the layer's input is a SELU output
+    add = t(synth.upstream_grad(B, N, ci, 991).astype(dt))
+    cache = op.NeighborCache(B, N, tdt, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
+    s = (2, 2, 2)
+    y_ref = op.selu(op.conv3p(tP, tX, tW, s, VOX, cache=cache))
+    dx_raw, dw_ref = op.conv3p_grad(tdY, tP, tX, tW, s, VOX, cache=cache)
+    tol = 1e-6 if dt == np.float32 else 1e-13
+    y = op.conv3p_layer(tP, tX, tW, s, VOX, cache)
+    assert rel_err(y.cpu().numpy(), y_ref.cpu().numpy()) <= tol
+    for a in (None, add):
+        dx_ref = op.selu_grad(tX, dx_raw, a)
+        dx, dw = op.conv3p_layer_grad(tdY, tP, tX, tW, s, VOX, cache, grad_addend=a)
+        assert rel_err(dx.cpu().numpy(), dx_ref.cpu().numpy()) <= tol
+        if (ci, co) == (5, 7):      # generic path: global float atomics, order not fixed
+            assert rel_err(dw.cpu().numpy(), dw_ref.cpu().numpy()) <= 10 * tol
+        else:
+            assert torch.equal(dw, dw_ref)
+
+
+def test_stack_fused_selu_matches_unfused(dev):
+    B, N = 4, 512
+    P = synth.modelnet_like(B, N, seed=995)
+    tP = torch.from_numpy(P).to(dev)
+    ups = [torch.from_numpy(synth.upstream_grad(B, N, stack.HIDDEN, 996 + i)).to(dev) for i in range(4)]
+    res = []
+    for fuse in (False, True):
+        st = stack.Conv3pStack(3, None, device=dev, seed=7, fuse_selu=fuse)
+        acts = st.forward(tP, tP.clone())
+        dx, fused = st.backward(ups)
+        res.append(([a.cpu().numpy() for a in acts], dx.cpu().numpy(), fused.cpu().numpy().copy()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert rel_err(b, a) <= 1e-6
+    assert rel_err(res[1][1], res[0][1]) <= 1e-6
+    assert rel_err(res[1][2], res[0][2]) <= 2e-6
