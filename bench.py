@@ -139,6 +139,12 @@ def main():
         distributed.allreduce_weight_grads(fused)
         return dx, fused
 
+    # CPython's full (generation-2) collection walks every object torch and numpy created at import: a ~40 ms
+    # host pause that hits once every few thousand allocations, i.e. somewhere inside a 100-step timed region
+    # (tools/stall_probe.py).  Freeze the setup objects, as latency-sensitive Python loops do.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     distributed.barrier()
@@ -146,6 +152,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueued = time.perf_counter() - t0       # host side done (diagnostic: is the step host- or GPU-bound?)
     torch.cuda.synchronize(dev)
     distributed.barrier()
     elapsed = distributed.max_over_ranks(time.perf_counter() - t0, dev)
@@ -170,6 +177,7 @@ def main():
     if rank == 0:
         total_pts = B_PER_GPU * N_POINTS * world
         ms_per_step = elapsed / args.steps * 1e3
+        host_ms_per_step = t_enqueued / args.steps * 1e3
         dom = max(kinds.items(), key=lambda kv: kv[1][1])[0] if kinds else None
         roofline = None
         if dom is not None:
@@ -197,7 +205,7 @@ def main():
                         "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in kinds.items()}}
         out = {"metric": "conv3p fwd+bwd Mpoints/s", "value": round(total_pts / (elapsed / args.steps) / 1e6, 3),
                "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(host_ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "cfg2 ModelNet40-shaped: B=32 clouds/GPU x N=2048, pointcnn2_acsd conv3p "
                                       "stack 3->9 s1, 9->9 s2, 9->9 s3, 9->9 s4 (+SELU), forward+backward, "
