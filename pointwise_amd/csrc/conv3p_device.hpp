@@ -157,6 +157,7 @@ template <typename T> struct Query {
     T ulo[3], uhi[3];   // union of the wave's 64 boxes (wave-uniform)
     float add[3];       // pre-filter addend: -lo*inv + shift (per lane)
     float thr[3];       // pre-filter half width incl. rounding slack (wave-uniform)
+    float cullo[3], culhi[3];   // range of pre-scaled candidate coordinates ANY lane of the wave can accept
     int orig;           // original index inside the cloud, -1 for padding lanes
 };
 
@@ -184,6 +185,15 @@ __device__ __forceinline__ void make_query(Query<T> &q, const PointRec<T> &me, c
         mag = fmaxf(mag, fmaxf(fabsf((float)q.ulo[a]), fabsf((float)q.uhi[a])) * st.inv[a]);
 #pragma unroll
     for (int a = 0; a < 3; ++a) q.thr[a] = st.halfw[a] + 1.0e-5f + 1.0e-6f * mag;
+    // The pre-filter accepts z = s + add (s = pre-scaled candidate coordinate) when z is within thr of a
+    // lattice point 0..mmax, i.e. only if s lies in [-thr - add, mmax + thr - add].  The union of that range
+    // over the wave's valid lanes (plus rounding slack) culls groups of 4 staged candidates (stage_tile).
+    const float slack = 1.0e-3f + 1.0e-5f * mag;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        q.cullo[a] = -q.thr[a] - wave_max(valid ? q.add[a] : -Limits<float>::inf()) - slack;
+        q.culhi[a] = st.mmax[a] + q.thr[a] - wave_min(valid ? q.add[a] : Limits<float>::inf()) + slack;
+    }
 }
 
 // tap lookup: tapmap[a*maxfull + t] = t/step[a] if t % step[a] == 0 else -1   (.cpp:285-288)
@@ -229,13 +239,34 @@ __device__ __forceinline__ int exact_tap(const PointRec<T> &v, const Query<T> &q
 // Stage one candidate tile for the pre-filter: lane l writes its point's fp32 coordinates, already
 // multiplied by inv = 1/(step*voxel), to the wave's SoA slot (soa[0..63] = x, [64..127] = y,
 // [128..191] = z), so that the per-pair arithmetic starts with a v_add instead of a v_fma.
+// Returns the quad mask: bits 4k..4k+3 are set iff the bounding box of candidates 4k..4k+3 (consecutive in
+// Morton order, so compact) meets the wave's acceptance range; scan_tile skips the other quads.
+__device__ __forceinline__ float quad_swap1(float v)   // lanes {0,1,2,3} -> {1,0,3,2}
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_swap2(float v)   // lanes {0,1,2,3} -> {2,3,0,1}
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
 template <typename T>
-__device__ __forceinline__ void stage_tile(float *soa, const PointRec<T> &cand, const Stencil<T> &st)
+__device__ __forceinline__ uint64_t stage_tile(float *soa, const PointRec<T> &cand, const Stencil<T> &st,
+                                               const Query<T> &q)
 {
     const int lane = threadIdx.x & 63;
-    soa[lane] = (float)cand.x * st.inv[0];
-    soa[64 + lane] = (float)cand.y * st.inv[1];
-    soa[128 + lane] = (float)cand.z * st.inv[2];
+    const float s[3] = {(float)cand.x * st.inv[0], (float)cand.y * st.inv[1], (float)cand.z * st.inv[2]};
+    soa[lane] = s[0];
+    soa[64 + lane] = s[1];
+    soa[128 + lane] = s[2];
+    bool ov = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float mn = fminf(s[a], quad_swap1(s[a])), mx = fmaxf(s[a], quad_swap1(s[a]));
+        mn = fminf(mn, quad_swap2(mn));
+        mx = fmaxf(mx, quad_swap2(mx));
+        ov &= (mx >= q.cullo[a]) & (mn <= q.culhi[a]);
+    }
+    return __ballot(ov);
 }
 
 // Pre-filter of the 64 staged candidates against the lane's query.  Candidate c ends up in bit
@@ -252,7 +283,7 @@ __device__ __forceinline__ void stage_tile(float *soa, const PointRec<T> &cand, 
 // coarser acceptance lengthened the pair lists enough to cancel the gain).
 template <typename T, bool ISO, bool TAPS3>
 __device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> &q, const Stencil<T> &st,
-                                               uint32_t &m0, uint32_t &m1)
+                                               uint64_t quads, uint32_t &m0, uint32_t &m1)
 {
     m0 = 0;
     m1 = 0;
@@ -261,6 +292,11 @@ __device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> 
     const float4 *sz = reinterpret_cast<const float4 *>(soa + 128);
 #pragma unroll
     for (int c4 = 0; c4 < 16; ++c4) {
+        if (((quads >> (4 * c4)) & 1) == 0) {   // wave-uniform: no lane can accept any of these 4 candidates
+            if (c4 < 8) m0 <<= 4;
+            else m1 <<= 4;
+            continue;
+        }
         const float4 X = sx[c4], Y = sy[c4], Z = sz[c4];   // wave-uniform address: LDS broadcast
         const float vx[4] = {X.x, X.y, X.z, X.w}, vy[4] = {Y.x, Y.y, Y.z, Y.w}, vz[4] = {Z.x, Z.y, Z.z, Z.w};
 #pragma unroll
@@ -293,15 +329,15 @@ __device__ __forceinline__ void scan_tile_impl(const float *soa, const Query<T> 
 }
 template <typename T>
 __device__ __forceinline__ void scan_tile(const float *soa, const Query<T> &q, const Stencil<T> &st,
-                                          uint32_t &m0, uint32_t &m1)
+                                          uint64_t quads, uint32_t &m0, uint32_t &m1)
 {
     // wave-uniform choice (kernel arguments + wave-uniform slack)
     const bool iso = q.thr[0] == q.thr[1] && q.thr[1] == q.thr[2];
     const bool taps3 = st.ext[0] == 3 && st.ext[1] == 3 && st.ext[2] == 3;
     if (iso && taps3)
-        scan_tile_impl<T, true, true>(soa, q, st, m0, m1);
+        scan_tile_impl<T, true, true>(soa, q, st, quads, m0, m1);
     else
-        scan_tile_impl<T, false, false>(soa, q, st, m0, m1);
+        scan_tile_impl<T, false, false>(soa, q, st, quads, m0, m1);
 }
 
 // Candidate tiles whose bounding box meets the union of the wave's filter boxes: 64 tiles per
@@ -361,10 +397,10 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
             tiles &= tiles - 1;
             if ((seen++ & (stride - 1)) != first) continue;   // stride is a power of two
             const PointRec<T> *tile = cloud_pts + (size_t)ct * kTile;
-            stage_tile(soa, tile[lane], st);
+            const uint64_t quads = stage_tile(soa, tile[lane], st, q);
             __builtin_amdgcn_wave_barrier();
             uint32_t m0, m1;
-            scan_tile(soa, q, st, m0, m1);
+            scan_tile(soa, q, st, quads, m0, m1);
             __builtin_amdgcn_wave_barrier();
             if (!qvalid) m0 = m1 = 0;
             for_each_bit(m0, m1, [&](int c) {

@@ -384,11 +384,11 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
             while (todo) {
                 const int ct = base + __builtin_ctzll(todo);
                 todo &= todo - 1;
-                stage_tile(soa, rec, st);
+                const uint64_t quads = stage_tile(soa, rec, st, q);
                 if (todo) rec = cloud_pts[(size_t)(base + __builtin_ctzll(todo)) * kTile + lane];   // prefetch
                 __builtin_amdgcn_wave_barrier();
                 uint32_t m0, m1;
-                if (CONV3P_ABLATE & 32) { m0 = m1 = 0; } else scan_tile(soa, q, st, m0, m1);
+                if (CONV3P_ABLATE & 32) { m0 = m1 = 0; } else scan_tile(soa, q, st, quads, m0, m1);
                 __builtin_amdgcn_wave_barrier();
                 if (!qvalid) m0 = m1 = 0;
                 masks[(size_t)(ct - ct0) * 64 + lane] = ((uint64_t)m1 << 32) | m0;
@@ -589,8 +589,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void f
     const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense path: centre and sub-lane of this thread
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    if (kSmall)
-        for (size_t e = threadIdx.x; e < nw; e += blockDim.x) w_lds[e] = filter[e];
+    if (kSmall) {
+        // filter -> LDS, 8 independent loads per thread in flight (one memory latency per batch, not per element)
+        for (uint32_t e0 = threadIdx.x; e0 < (uint32_t)nw; e0 += 8 * 256) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = e0 + u * 256 < (uint32_t)nw ? filter[e0 + u * 256] : (T)0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 256 < (uint32_t)nw) w_lds[e0 + u * 256] = v[u];
+        }
+    }
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;   // uniform
     if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
@@ -760,13 +769,28 @@ __global__ __launch_bounds__(256) void backward_kernel(
     const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense phase A: centre and sub-lane
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    if (kSmall) {
-        for (int e = threadIdx.x; e < (int)nw; e += blockDim.x) {
-            const int row = e / CIN, k = e - row * CIN;
-            const int f = row / COUT, c = row - f * COUT;
-            wt[e] = filter[((size_t)f * CIN + k) * COUT + c];
+    if constexpr (kSmall) {
+        // filter -> LDS transposed to [row = (f,c)][k]: coalesced global reads, 8 per thread in flight
+        for (uint32_t e0 = threadIdx.x; e0 < (uint32_t)nw; e0 += 8 * 256) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = e0 + u * 256 < (uint32_t)nw ? filter[e0 + u * 256] : (T)0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t e = e0 + u * 256;   // e = (f*CIN + k)*COUT + c
+                if (e < (uint32_t)nw) {
+                    const uint32_t fk = e / COUT, c = e - fk * COUT;
+                    const uint32_t f = fk / CIN, k = fk - f * CIN;
+                    wt[(f * COUT + c) * CIN + k] = v[u];
+                }
+            }
         }
-        for (int e = threadIdx.x; e < nrows * kCntStride; e += blockDim.x) G[e] = (T)0;
+        // G = 0, 16 bytes per store (G is 16-byte aligned, its length is padded to 4 by the LDS carve-up)
+        {
+            float4 *G4 = reinterpret_cast<float4 *>(G);
+            const int n4 = (int)((nrows * kCntStride * sizeof(T) + 15) / 16);
+            for (int e = threadIdx.x; e < n4; e += blockDim.x) G4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 
     int b, qt;
