@@ -163,6 +163,18 @@ int conv3p_cache_prepare_f64(const double *points, const int32_t *stride_xyz, do
                              int N, int fz, int fy, int fx, void *cache, size_t cache_bytes,
                              const conv3p_cache_config *cfg, void *stream);
 
+/* The same for n_strides stencils that share filter extents, voxel size and points (the layers of the
+ * reference's models: strides 1..4, pointcnn2_acsd.py:47-65) with one sort, ONE search launch and ONE
+ * normaliser launch: stride_xyz is int32[n_strides][3] on the host, n_strides <= 8 and <= cfg->slots.  A single
+ * search launch is one round of workgroups whose duration is set by its slowest tile; batched, the stencils
+ * fill each other's tails. */
+int conv3p_cache_prepare_multi_f32(const float *points, const int32_t *strides_xyz, int n_strides,
+                                   float voxel_size, int B, int N, int fz, int fy, int fx, void *cache,
+                                   size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+int conv3p_cache_prepare_multi_f64(const double *points, const int32_t *strides_xyz, int n_strides,
+                                   double voxel_size, int B, int N, int fz, int fy, int fx, void *cache,
+                                   size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+
 /* Per-point, per-tap neighbour populations, int32 (B, N, fz*fy*fx) on the device.
  * Restates Grid::neighbor_count / kernelBuildNeighborCount
  * (tf_conv3p_atrous.cpp:306-379 / tf_conv3p_atrous.cu:288-343): the intermediate both

@@ -37,6 +37,7 @@ def _sig(real):
         "layer_backward_cached": (_i, [_vp, _vp, _vp, _vp, _vp, real, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                        _vp, _vp]),
         "cache_prepare": (_i, [_vp, _vp, real, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+        "cache_prepare_multi": (_i, [_vp, _vp, _i, real, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
         "neighbor_count": (_i, [_vp, _vp, real, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
         "selu": (_i, [_vp, _vp, _sz, _vp]),
         "selu_grad": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -265,6 +265,31 @@ def cache_prepare(points, filter_zyx, stride, voxel_size, cache, points_unchange
               st.cuda_stream)
 
 
+def cache_prepare_multi(points, filter_zyx, strides, voxel_size, cache, points_unchanged=False, stream=None):
+    """cache_prepare for several strides at once (conv3p_cache_prepare_multi_*): one sort, one search launch and
+    one normaliser launch for all of them."""
+    lib = _lib.load()
+    _require(points.dim() == 3 and points.shape[2] == 3, "Conv3p expects (batch_size, num_points, 3) points shape")
+    dev = _check_device(points)
+    sfx, creal, esz = _SFX[points.dtype]
+    vox = _voxel_value(voxel_size)
+    B, N, _ = points.shape
+    fz, fy, fx = [int(v) for v in filter_zyx]
+    flat = []
+    for st in strides:
+        flat.extend(list(_stride_list(st)))
+    K = len(flat) // 3
+    arr = (ctypes.c_int32 * len(flat))(*flat)
+    if not cache.fits(B, N, points.dtype, dev, fz * fy * fx, 0, 0):
+        raise Conv3pInvalidArgument("neighbour cache does not fit these clouds")
+    points = points.contiguous()
+    with torch.cuda.device(dev):
+        st_ = stream if stream is not None else torch.cuda.current_stream(dev)
+        _call(getattr(lib, "conv3p_cache_prepare_multi_" + sfx), points.data_ptr(), ctypes.cast(arr, ctypes.c_void_p),
+              K, creal(vox), B, N, fz, fy, fx, cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(points_unchanged),
+              st_.cuda_stream)
+
+
 def neighbor_count(points, filter_zyx, stride, voxel_size):
     """int32 (B, N, fz*fy*fx) per-tap neighbour populations (the op's normaliser), for exact parity checks."""
     lib = _lib.load()

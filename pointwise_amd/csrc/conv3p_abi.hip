@@ -670,6 +670,61 @@ int prepare_impl(const T *points, const int32_t *stride, T voxel, int B, int N, 
     return run_search<T>(c, c.L.slot[c.slot].count, true);
 }
 
+// geometry of K stencils (same filter extents, K strides) over the same points: one prep, ONE search launch and
+// ONE finalise launch for all of them
+template <typename T>
+int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, int B, int N, int fz, int fy,
+                       int fx, Where wh, void *stream)
+{
+    if (K <= 0 || K > kMaxJobs || !strides) return CONV3P_ERR_INVALID_ARGUMENT;
+    Dims d{B, N, 0, 0, fz, fy, fx, 0, 0};
+    for (int k = 0; k < K; ++k) TRY(check(d, strides + 3 * k, (double)voxel, false));
+    if ((size_t)B * N == 0) return CONV3P_OK;
+    if (!points) return CONV3P_ERR_INVALID_ARGUMENT;
+    if (K > wh.nslots) return CONV3P_ERR_WORKSPACE;     // the stencils would evict each other
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SearchJobs<T> jobs;
+    int njobs = 0;
+    size_t lds = 0;
+    Call<T> c;
+    for (int k = 0; k < K; ++k) {
+        TRY(begin_call<T>(c, d, strides + 3 * k, voxel, 0, wh, s));
+        TRY(run_prep<T>(points, c));
+        wh.flags |= CONV3P_CACHE_POINTS_UNCHANGED;      // the other stencils see the same points
+        if (c.skip_search) continue;
+        const Stencil<T> &st = c.st;
+        const auto &S = c.L.slot[c.slot];
+        const size_t l = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) +
+                         a16((size_t)c.L.gtiles * 64 * 8) + a16((size_t)c.L.gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
+                         a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
+        if (l > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
+        lds = l > lds ? l : lds;
+        SearchJob<T> &j = jobs.job[njobs++];
+        j.st = st;
+        j.cc = c.cc;
+        j.count = S.count;
+        j.pairs = S.pairs;
+        j.segs = S.segs;
+        j.qsegs = S.qsegs;
+    }
+    if (njobs == 0) return CONV3P_OK;
+    const BlockMap bm = make_blockmap(c.d);
+    {
+        Scope sc(K_SEARCH, s);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(search_multi_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(search_multi_kernel<T>, dim3(grid_of(bm), njobs), dim3(256), lds, s, c.L.pts, c.L.boxes,
+                           c.d.N, c.d.ntiles, c.L.gtiles, c.L.ngroups, bm, jobs);
+    }
+    TRY(hip_ok());
+    {
+        Scope sc2(K_FINALISE, s);
+        hipLaunchKernelGGL(finalise_multi_kernel<T>, dim3(grid_of(bm), njobs), dim3(256), 0, s, c.L.pts, c.d.N,
+                           c.d.ntiles, c.L.ngroups, bm, jobs);
+    }
+    return hip_ok();
+}
+
 template <typename T>
 int backward_impl(const T *grad_out, const T *points, const T *input, const T *filter,
                   const int32_t *stride, T voxel, int B, int N, int Cin, int Cout, int fz, int fy, int fx,
@@ -926,6 +981,21 @@ int conv3p_cache_prepare_f64(const double *points, const int32_t *stride_xyz, do
 {
     if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
     return prepare_impl<double>(points, stride_xyz, voxel_size, B, N, fz, fy, fx, CACHE_WHERE(8), stream);
+}
+
+int conv3p_cache_prepare_multi_f32(const float *points, const int32_t *strides_xyz, int n_strides,
+                                   float voxel_size, int B, int N, int fz, int fy, int fx, CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return prepare_multi_impl<float>(points, strides_xyz, n_strides, voxel_size, B, N, fz, fy, fx, CACHE_WHERE(4),
+                                     stream);
+}
+int conv3p_cache_prepare_multi_f64(const double *points, const int32_t *strides_xyz, int n_strides,
+                                   double voxel_size, int B, int N, int fz, int fy, int fx, CACHE_ARGS)
+{
+    if (!cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    return prepare_multi_impl<double>(points, strides_xyz, n_strides, voxel_size, B, N, fz, fy, fx, CACHE_WHERE(8),
+                                      stream);
 }
 
 int conv3p_neighbor_count_f32(const float *points, const int32_t *stride_xyz, float voxel_size, int B,

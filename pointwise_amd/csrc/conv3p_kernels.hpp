@@ -350,12 +350,11 @@ __device__ __forceinline__ uint32_t backward_tap(const T *p, const PointRec<T> &
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restrict__ pts,
-                                                     const T *__restrict__ boxes, Stencil<T> st, int N,
-                                                     int ntiles, int gtiles, int ngroups, BlockMap bm,
-                                                     int32_t *__restrict__ count,
-                                                     PairEntry *__restrict__ pairs, CacheCtl cc,
-                                                     uint2 *__restrict__ segs, uint2 *__restrict__ qsegs)
+__device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes,
+                                            const Stencil<T> &st, int N, int ntiles, int gtiles, int ngroups,
+                                            const BlockMap &bm, int32_t *__restrict__ count,
+                                            PairEntry *__restrict__ pairs, const CacheCtl &cc,
+                                            uint2 *__restrict__ segs, uint2 *__restrict__ qsegs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
@@ -538,16 +537,51 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
         }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restrict__ pts,
+                                                     const T *__restrict__ boxes, Stencil<T> st, int N,
+                                                     int ntiles, int gtiles, int ngroups, BlockMap bm,
+                                                     int32_t *__restrict__ count,
+                                                     PairEntry *__restrict__ pairs, CacheCtl cc,
+                                                     uint2 *__restrict__ segs, uint2 *__restrict__ qsegs)
+{
+    search_tile<T>(pts, boxes, st, N, ntiles, gtiles, ngroups, bm, count, pairs, cc, segs, qsegs);
+}
+
+// Several stencils over the same sorted points in ONE launch (blockIdx.y = stencil): the models' layers share
+// `points` and differ only in stride, and one search launch is a single round of workgroups whose duration is
+// set by its slowest tile; batched, the light tiles of one stencil fill in behind the heavy tiles of another.
+constexpr int kMaxJobs = 8;
+template <typename T> struct SearchJob {
+    Stencil<T> st;
+    CacheCtl cc;
+    int32_t *count;
+    PairEntry *pairs;
+    uint2 *segs, *qsegs;
+};
+template <typename T> struct SearchJobs {
+    SearchJob<T> job[kMaxJobs];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void search_multi_kernel(const PointRec<T> *__restrict__ pts,
+                                                           const T *__restrict__ boxes, int N, int ntiles,
+                                                           int gtiles, int ngroups, BlockMap bm,
+                                                           SearchJobs<T> jobs)
+{
+    const SearchJob<T> &j = jobs.job[blockIdx.y];
+    search_tile<T>(pts, boxes, j.st, N, ntiles, gtiles, ngroups, bm, j.count, j.pairs, j.cc, j.segs, j.qsegs);
+}
+
 // ---------------------------------------------------------------------------------
 // finalise: once every population is known, store the two normalisers of each pair
 // (dense, thread = pair).  rcp = 1 / (float)count is the correctly rounded IEEE quotient.
 // ---------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__restrict__ pts,
-                                                       const int32_t *__restrict__ count, int N, int ntiles,
-                                                       int ngroups, int ntap, BlockMap bm,
-                                                       PairEntry *__restrict__ pairs,
-                                                       const uint2 *__restrict__ segs, CacheCtl cc)
+__device__ __forceinline__ void finalise_tile(const PointRec<T> *__restrict__ pts,
+                                              const int32_t *__restrict__ count, int N, int ntiles,
+                                              int ngroups, int ntap, const BlockMap &bm,
+                                              PairEntry *__restrict__ pairs,
+                                              const uint2 *__restrict__ segs, const CacheCtl &cc)
 {
     __shared__ int32_t qorig[64];
     int b, qt;
@@ -575,6 +609,24 @@ __global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__rest
             pe[e] = en;                                                              // one 16-byte store
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__restrict__ pts,
+                                                       const int32_t *__restrict__ count, int N, int ntiles,
+                                                       int ngroups, int ntap, BlockMap bm,
+                                                       PairEntry *__restrict__ pairs,
+                                                       const uint2 *__restrict__ segs, CacheCtl cc)
+{
+    finalise_tile<T>(pts, count, N, ntiles, ngroups, ntap, bm, pairs, segs, cc);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void finalise_multi_kernel(const PointRec<T> *__restrict__ pts, int N,
+                                                             int ntiles, int ngroups, BlockMap bm,
+                                                             SearchJobs<T> jobs)
+{
+    const SearchJob<T> &j = jobs.job[blockIdx.y];
+    finalise_tile<T>(pts, j.count, N, ntiles, ngroups, j.st.ntap, bm, j.pairs, j.segs, j.cc);
 }
 
 // ---------------------------------------------------------------------------------

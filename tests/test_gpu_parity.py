@@ -454,3 +454,68 @@ def test_stack_fused_selu_matches_unfused(dev):
         assert rel_err(b, a) <= 1e-6
     assert rel_err(res[1][1], res[0][1]) <= 1e-6
     assert rel_err(res[1][2], res[0][2]) <= 2e-6
+
+
+def test_cache_prepare_multi_equals_per_stencil_prepare(dev):
+    """One batched search launch for strides 1..4 gives the same lists (hence bitwise the same op results) as
+    four separate prepares; a second multi call on unchanged points launches nothing new and stays valid."""
+    B, N = 3, 700
+    P, X, W, dY = make_case("modelnet", B, N, 9, 9, seed=1001)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tP, tX, tW, tdY = t(P), t(X), t(W), t(dY)
+    strides = [(1, 1, 1), (2, 2, 2), (3, 3, 3), (4, 4, 4)]
+    mk = lambda: op.NeighborCache(B, N, torch.float32, dev, slots=4, max_taps=27, max_cin=9, max_cout=9)
+    ca, cb = mk(), mk()
+    for s in strides:
+        op.cache_prepare(tP, (3, 3, 3), s, VOX, ca, points_unchanged=s != strides[0])
+    op.cache_prepare_multi(tP, (3, 3, 3), strides, VOX, cb)
+    op.cache_prepare_multi(tP, (3, 3, 3), strides, VOX, cb, points_unchanged=True)
+    for s in strides:
+        ya = op.conv3p(tP, tX, tW, s, VOX, cache=ca, points_unchanged=True)
+        yb = op.conv3p(tP, tX, tW, s, VOX, cache=cb, points_unchanged=True)
+        assert torch.equal(ya, yb)
+        da = op.conv3p_grad(tdY, tP, tX, tW, s, VOX, cache=ca, points_unchanged=True)
+        db = op.conv3p_grad(tdY, tP, tX, tW, s, VOX, cache=cb, points_unchanged=True)
+        assert torch.equal(da[0], db[0]) and torch.equal(da[1], db[1])
+        assert rel_err(yb.cpu().numpy(), oracle.forward(P, X, W, s, VOX)) <= 1e-5
+    # new points through the multi entry: everything is rebuilt
+    P2 = synth.modelnet_like(B, N, seed=1002)
+    tP2 = t(P2)
+    op.cache_prepare_multi(tP2, (3, 3, 3), strides, VOX, cb)
+    y2 = op.conv3p(tP2, tX, tW, (3, 3, 3), VOX, cache=cb, points_unchanged=True)
+    assert rel_err(y2.cpu().numpy(), oracle.forward(P2, X, W, (3, 3, 3), VOX)) <= 1e-5
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_stack_prefetch_orders_and_batched_search(dev, batched):
+    """prefetch() right after forward() (the bench's order), prefetch() BEFORE the forward of the batch that was
+    prefetched earlier (two prefetches outstanding), and the one-launch search all give the results of a stack
+    that never prefetches."""
+    B, N = 3, 320
+    Ps = [torch.from_numpy(synth.modelnet_like(B, N, seed=1010 + i)).to(dev) for i in range(3)]
+    ups = [torch.from_numpy(synth.upstream_grad(B, N, stack.HIDDEN, 1020 + i)).to(dev) for i in range(4)]
+
+    def run(mode):
+        st = stack.Conv3pStack(3, None, device=dev, seed=11)
+        st.batched_prefetch = batched
+        out = []
+        if mode == "early":
+            st.prefetch(Ps[0])
+        for i in range(5):
+            cur, nxt = Ps[i % 3], Ps[(i + 1) % 3]
+            if mode == "early":
+                st.prefetch(nxt)
+            acts = st.forward(cur, cur)
+            if mode == "late":
+                st.prefetch(nxt)
+            dx, fused = st.backward(ups)
+            out.append((acts[3].clone(), dx.clone(), fused.clone()))
+        torch.cuda.synchronize()
+        return out
+
+    ref = run("none")
+    for mode in ("late", "early"):
+        got = run(mode)
+        for r, g in zip(ref, got):
+            for a, b in zip(r, g):
+                assert torch.equal(a, b), mode
