@@ -519,3 +519,17 @@ def test_stack_prefetch_orders_and_batched_search(dev, batched):
         for r, g in zip(ref, got):
             for a, b in zip(r, g):
                 assert torch.equal(a, b), mode
+
+
+def test_cloud_larger_than_the_lds_sort(dev):
+    """N > 16384: the cloud does not fit the LDS sort, prep_kernel keeps the caller's order (loose tiles, same
+    decisions).  Also exercises several 64-tile ballots of candidate tiles."""
+    B, N = 1, 17000
+    P = synth.room_like(B, N, 1030, extent=(3.0, 3.0, 2.0))
+    X = synth.features(B, N, 3, 1031, points=P)
+    W = synth.filter_weights(3, 3, 3, 3, 9, 1032)
+    dY = synth.upstream_grad(B, N, 9, 1033)
+    s = (2, 2, 2)
+    ref = (oracle.neighbor_count(P, (3, 3, 3), s, VOX), oracle.forward(P, X, W, s, VOX, nthreads=8)) + \
+        oracle.backward(dY, P, X, W, s, VOX, nthreads=1)
+    check_against(ref, run_hip(dev, P, X, W, dY, s), np.float32)
