@@ -15,7 +15,9 @@
 #include "conv3p_kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -29,11 +31,11 @@ inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 // ----------------------------------------------------------------------------- profiling
 enum Kind { K_PREP = 0, K_SEARCH, K_FINALISE, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET,
-            K_DEEP_GEMM, K_DEEP_DW, K_TRANSPOSE, K_NKINDS };
+            K_DEEP_GEMM, K_DEEP_DW, K_TRANSPOSE, K_DEEP_ORDER, K_NKINDS };
 const char *const kKindName[K_NKINDS] = {"prep_kernel", "search_kernel", "finalise_kernel", "forward_kernel",
                                          "backward_kernel", "reduce_partials_kernel", "selu_kernel",
                                          "selu_grad_kernel", "memset", "deep_gemm_kernel", "deep_dw_kernel",
-                                         "transpose_filter_kernel"};
+                                         "transpose_filter_kernel", "deep_order_kernel"};
 struct Prof {
     std::mutex mu;
     bool on = false;
@@ -427,8 +429,7 @@ inline bool deep_shape(int elem, int cin, int cout)
 
 struct DeepScratch {   // carved from the per-call scratch region
     float *wt;             // filter transposed [F][Cout][Cin]
-    uint16_t *bucket_order;   // per pair slot: centre-major, tap-sorted record order
-    uint32_t *tap_order;      // per pair slot: tile tap-major record order (backward)
+    uint32_t *tap_order;   // per pair slot: tile tap-major record order
     uint32_t *tap_off;     // [tiles][F+1]
     uint8_t *tile_flag;    // [tiles]
     float *partials;       // [nchunks + 1][F*Cin*Cout]
@@ -443,11 +444,17 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     char *p = static_cast<char *>(base);
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
-    const int slices = d.Cout / 64;
-    s.nchunks = 512 / (d.ntap * slices) > 1 ? 512 / (d.ntap * slices) : 1;
-    if (s.nchunks > 16) s.nchunks = 16;
+    // (tap, chunk) grid of deep_dw_kernel: ~3 rounds of workgroups at 2 per CU, so that the taps with many pairs
+    // (whose workgroups run longest, and are launched first) do not set the kernel's duration
+    s.nchunks = 1728 / d.ntap > 1 ? 1728 / d.ntap : 1;
+    const int tiles = d.B * d.ntiles;
+    if (s.nchunks > tiles) s.nchunks = tiles > 0 ? tiles : 1;
+    if (s.nchunks > 64) s.nchunks = 64;
+    if (const char *e = getenv("CONV3P_DW_CHUNKS")) {        // developer override (tools/deep_time.py)
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) s.nchunks = v;
+    }
     s.wt = reinterpret_cast<float *>(take(nw * 4));
-    s.bucket_order = reinterpret_cast<uint16_t *>(take(pair_slots * 2));
     s.tap_order = reinterpret_cast<uint32_t *>(take(pair_slots * 4));
     s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
@@ -458,21 +465,32 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
 
 size_t deep_scratch_bytes(const Dims &d, size_t pair_slots) { return carve_deep(d, pair_slots, nullptr).bytes; }
 
+template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratch &ds)
+{
+    const Dims &d = c.d;
+    if (d.ntap > 64) return CONV3P_ERR_UNSUPPORTED;
+    const auto &S = c.L.slot[c.slot];
+    const size_t lds = (size_t)18 * d.ntap * 4;
+    Scope sc(K_DEEP_ORDER, c.s);
+    hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, S.pairs, S.segs,
+                       d.ntap, ds.tap_order, ds.tap_off, ds.tile_flag);
+    return hip_ok();
+}
+
 template <int KD, int ND, bool BWD>
 int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, float *out, const DeepScratch &ds)
 {
     const Dims &d = c.d;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = a16((size_t)64 * (KD + 1) * 4) + a16((size_t)64 * (d.ntap + 1) * 2) + 256 + 256 +
-                       a16((size_t)d.ntap * 4) + 256;
+    const size_t a = (size_t)64 * (KD + 1) * 4, r = (size_t)kDeepBlk * (KD + 32) * 4;
+    const size_t lds = a16(a > r ? a : r) + 3 * (size_t)kDeepBatch * 4 + 256;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_DEEP_GEMM, c.s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_gemm_kernel<KD, ND, BWD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((deep_gemm_kernel<KD, ND, BWD>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs,
-                       S.segs, S.qsegs, src, Bm, d.N, d.ntiles, d.ntap, bm, out, ds.bucket_order, ds.tap_order,
-                       ds.tap_off, ds.tile_flag);
+                       S.segs, src, Bm, d.N, d.ntiles, d.ntap, bm, out, ds.tap_order, ds.tap_off, ds.tile_flag);
     return hip_ok();
 }
 
@@ -480,8 +498,9 @@ template <int CI, int CO>
 int deep_forward(const Call<float> &c, const float *input, const float *filter, float *output)
 {
     const DeepScratch ds = carve_deep(c.d, (size_t)c.d.B * c.L.pairs_per_cloud, c.L.partials);
+    TRY(launch_deep_order<false>(c, ds));
     TRY((launch_deep_gemm<CI, CO, false>(c, input, filter, output, ds)));
-    // tiles the deep kernel could not take (pair buffer overflow): generic kernel, flagged tiles only
+    // tiles the deep kernels could not take (pair buffer overflow, non-finite rows): generic kernel, flagged tiles
     return launch_forward<float, 0, 0>(c, input, filter, output, ds.tile_flag);
 }
 
@@ -493,22 +512,37 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)d.ntap * CI * CO;
     const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials);
+    TRY(launch_deep_order<true>(c, ds));
     {
         Scope sc(K_TRANSPOSE, c.s);
         hipLaunchKernelGGL(transpose_filter_kernel, dim3((unsigned)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024)),
                            dim3(256), 0, c.s, filter, d.ntap, CI, CO, ds.wt);
     }
     TRY(hip_ok());
-    // dX = sum_f' G_f' . W[f']^T  (K = Cout, N = Cin); also publishes the tap-major record order
+    // dX = sum_f' G_f' . W[f']^T  (K = Cout, N = Cin)
     TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds)));
     {
-        const size_t lds = a16((size_t)64 * (CI + 1) * 4) + a16((size_t)64 * 65 * 4);
+        const size_t lds = a16((size_t)65 * (CI + 1) * 4) + a16((size_t)kDeepBlk * (CO + 32) * 4) +
+                           3 * (size_t)kDeepBatch * 4 + 256 + ((CONV3P_ABLATE & 8388608) ? 20000 : 0);
+        if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
         Scope sc(K_DEEP_DW, c.s);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_dw_kernel<CI, CO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(d.ntap, CO / 64, ds.nchunks), dim3(256), lds, c.s, c.L.pts,
-                           S.pairs, S.segs, ds.tap_order, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap,
-                           ds.nchunks, ds.partials);
+        // taps by distance from the stencil centre (ties: ascending tap index)
+        TapPerm perm;
+        {
+            int order[64], key[64];
+            for (int f = 0; f < d.ntap; ++f) {
+                const int tx = f % d.fx, ty = (f / d.fx) % d.fy, tz = f / (d.fx * d.fy);
+                key[f] = abs(2 * tx - (d.fx - 1)) + abs(2 * ty - (d.fy - 1)) + abs(2 * tz - (d.fz - 1));
+                order[f] = f;
+            }
+            std::stable_sort(order, order + d.ntap, [&](int a, int b) { return key[a] < key[b]; });
+            for (int f = 0; f < 64; ++f) perm.t[f] = (uint8_t)(f < d.ntap ? order[f] : 0);
+        }
+        hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(d.ntap, ds.nchunks), dim3(256), lds, c.s, c.L.pts, S.pairs,
+                           S.segs, ds.tap_order, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap, ds.nchunks,
+                           ds.tile_flag, perm, ds.partials);
     }
     TRY(hip_ok());
     // flagged tiles: generic kernel adds into the zeroed rows / into the extra partial slot

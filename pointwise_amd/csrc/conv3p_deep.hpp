@@ -3,11 +3,19 @@
 // For wide layers the per-pair form (Cin*Cout FMAs per neighbour pair) is wasteful; the op factorises as
 //     out[i,:]  = sum_f  M_f[i,:]  . W[f]          M_f[i,:] = sum_{j in tap f of i} x[j,:] / count[i,f]
 //     dX[j,:]   = sum_f' G_f'[j,:] . W[f']^T       G_f'[j,:] = sum_{ii: bwd tap f'} dY[ii,:] / count[ii,f']
-//     dW[f']    = sum_j  X[j,:]^T . G_f'[j,:]
+//     dW[f']    = sum_pairs(f')  x[j,:]^T . (dY[ii,:] / count[ii,f'])
 // (same sums as tf_conv3p_atrous.cpp:480-494 and :682-698, re-associated; inside the fp32 tolerance).
-// M_f / G_f' are built per query tile and per tap in LDS from the pair lists (gather-reduce, lanes = channels,
-// coalesced 4*K-byte rows), and every product is a [64 x K].[K x N] GEMM on v_mfma_f32_32x32x2_f32 -- exact
-// fp32 (an fmaf chain), 64 FLOP/clk/SIMD.  Taps with no neighbour in the tile are skipped.
+// Everything, including the per-centre reductions M_f / G_f', runs on v_mfma_f32_32x32x2_f32 (exact fp32, an
+// fmaf chain per output, 64 FLOP/clk/SIMD):
+//   * a tile's records are put in tap-major order once (deep_order_kernel, a stable counting sort);
+//   * per tap, the neighbour rows of 32 records at a time are COPIED into LDS (coalesced, whole rows, the next
+//     block's loads in flight under the current block's MFMAs) -- no per-centre serial gather chains;
+//   * M_f = S_f . rows, where S_f[centre][record] = 1/count if the record belongs to the centre, else 0, is built
+//     in the A-operand registers on the fly (one compare + select per MFMA step);
+//   * M_f . W[f] follows from LDS, the W[f] operand streamed from L2 sixteen k-rows ahead;
+//   * dW[f'] = X_tile^T . (dY rows / count) needs no per-centre reduction at all: the pair index is the GEMM's
+//     k dimension.
+// Taps with no neighbour in the tile are skipped.
 //
 // Fragment layouts of mfma_f32_32x32x2f32 (cdna_hip_programming.md section 3):
 //   A operand: lane l holds A[i = l & 31][k = l >> 5];  B operand: lane l holds B[k = l >> 5][j = l & 31];
@@ -16,350 +24,530 @@
 
 #include "conv3p_device.hpp"
 
+#ifndef CONV3P_ABLATE
+#define CONV3P_ABLATE 0
+#endif
+#ifndef DEEP_GEMM_WAVES
+#define DEEP_GEMM_WAVES 2
+#endif
+
 namespace conv3p {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+constexpr int kDeepBlk = 32;      // records per staged block (= 16 MFMA k-steps)
+constexpr int kDeepBatch = 256;   // records whose metadata is fetched at once
 
-// Per-centre stable bucketing of a tile's pair records by tap (lane = centre, wave 0 only).
-//   start[q*(ntap+1) + f] .. start[q*(ntap+1) + f+1]  : positions (relative to the centre's bucket base) of tap f
-//   order[qbase[q] + p]                               : record index relative to the CENTRE's list start
-//                                                       (u16: a centre has < 65536 neighbours); `order` lives in
-//                                                       global scratch, one u16 per pair slot of the tile
-// Returns (through total[f]) the number of records of each tap in the whole tile.
+// ---------------------------------------------------------------------------------------------
+// deep_order_kernel: tap-major order of every query tile's records (stable counting sort by tap: taps ascending,
+// inside a tap the search's record order -> deterministic).  One workgroup per tile.
+//   tap_off[tile][f] .. tap_off[tile][f+1] : slots of tap f (relative to the tile's segment)
+//   tap_order[segment start + slot]        : record index relative to the tile's segment
+// BWD: taps = backward taps, records with rcp_bwd == 0 dropped; else forward taps, false positives dropped.
+// Tiles whose pair reservation overflowed get an empty order and tile_flag = 1 (the generic kernel takes them).
+// ---------------------------------------------------------------------------------------------
 template <bool BWD>
-__device__ __forceinline__ void bucket_by_tap(const PairEntry *__restrict__ seg, const uint2 *__restrict__ qseg_tile,
-                                              uint32_t seg_start, int ntap, uint16_t *start,
-                                              uint16_t *__restrict__ order, uint32_t *qbase, uint32_t *total)
+__global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__restrict__ pairs,
+                                                         const uint2 *__restrict__ segs, int ntap,
+                                                         uint32_t *__restrict__ tap_order,
+                                                         uint32_t *__restrict__ tap_off,
+                                                         uint8_t *__restrict__ tile_flag)
 {
-    const int lane = threadIdx.x & 63;
-    if ((threadIdx.x >> 6) == 0) {
-        const uint2 sg = qseg_tile[lane];
-        const uint32_t n = sg.y, rel = sg.x - seg_start;
-        uint16_t *st = start + lane * (ntap + 1);
-        for (int f = 0; f <= ntap; ++f) st[f] = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            const PairEntry en = seg[rel + i];
-            const uint32_t f = BWD ? code_bwd(en.code) : code_fwd(en.code);
-            const bool ok = BWD ? (en.rcp_bwd > 0.0f) : (code_fwd(en.code) != kNoTap);
-            if (ok) st[f + 1] += 1;
-        }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *tot = reinterpret_cast<uint32_t *>(smem);            // [ntap]     records per tap (whole tile)
+    uint32_t *base = tot + ntap;                                    // [ntap]     next free slot of each tap
+    uint32_t *wcnt = base + ntap;                                   // [16][ntap] per wave-chunk counts of a super-chunk
+    const size_t tile = blockIdx.x;
+    const uint2 tseg = segs[tile];                                  // ngroups == 1 on this path (host checks)
+    uint32_t *toff = tap_off + tile * (size_t)(ntap + 1);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tseg.y == kSegOverflow) {
+        for (uint32_t f = tid; f <= (uint32_t)ntap; f += 256) toff[f] = 0;
+        if (tid == 0) tile_flag[tile] = 1;
+        return;
+    }
+    if (tid == 0) tile_flag[tile] = 0;
+    const PairEntry *seg = pairs + tseg.x;
+    const uint32_t n = tseg.y;
+    auto key_of = [&](const PairEntry &en) -> uint32_t {
+        const bool ok = BWD ? (en.rcp_bwd > 0.0f) : (code_fwd(en.code) != kNoTap);
+        return ok ? (BWD ? code_bwd(en.code) : code_fwd(en.code)) : 0xFFFFFFFFu;
+    };
+    for (uint32_t f = tid; f < (uint32_t)ntap; f += 256) tot[f] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256) {                       // totals: order-independent, LDS atomics
+        const uint32_t k = key_of(seg[i]);
+        if (k != 0xFFFFFFFFu) atomicAdd(&tot[k], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
         uint32_t run = 0;
-        for (int f = 0; f < ntap; ++f) {     // counts -> exclusive starts (st[f+1] held the count of tap f)
-            const uint32_t c = st[f + 1];
-            st[f] = (uint16_t)run;
-            run += c;
+        for (int f = 0; f < ntap; ++f) {
+            toff[f] = run;
+            base[f] = run;
+            run += tot[f];
         }
-        st[ntap] = (uint16_t)run;
-        int tot;
-        const uint32_t base = (uint32_t)wave_excl_scan((int)run, tot);
-        qbase[lane] = base;
-        // second pass: stable scatter (st[f] is advanced and restored afterwards)
-        for (uint32_t i = 0; i < n; ++i) {
-            const PairEntry en = seg[rel + i];
-            const uint32_t f = BWD ? code_bwd(en.code) : code_fwd(en.code);
-            const bool ok = BWD ? (en.rcp_bwd > 0.0f) : (code_fwd(en.code) != kNoTap);
-            if (ok) {
-                order[base + st[f]] = (uint16_t)i;
-                st[f] += 1;
+        toff[ntap] = run;
+    }
+    __syncthreads();
+    // stable ranks, 1024 records (4 per thread, 16 wave-chunks of 64 consecutive records) per round
+    uint32_t *ord = tap_order + tseg.x;
+    for (uint32_t s0 = 0; s0 < n; s0 += 1024) {
+        uint32_t key[4], rank[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = s0 + (uint32_t)u * 256u + tid;
+            key[u] = i < n ? key_of(seg[i]) : 0xFFFFFFFFu;
+            rank[u] = 0;
+        }
+        for (int f = 0; f < ntap; ++f) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t m = __ballot(key[u] == (uint32_t)f);
+                if (key[u] == (uint32_t)f)
+                    rank[u] = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                if (lane == 0) wcnt[((uint32_t)u * 4u + wave) * (uint32_t)ntap + (uint32_t)f] = (uint32_t)__popcll(m);
             }
         }
-        // st[f] now holds the END of tap f == start of tap f+1: shift back to starts
-        uint32_t prev = 0;
-        for (int f = 0; f < ntap; ++f) {
-            const uint32_t end = st[f];
-            st[f] = (uint16_t)prev;
-            prev = end;
+        __syncthreads();
+        if (tid < (uint32_t)ntap) {                                 // exclusive offsets over the 16 wave-chunks
+            uint32_t run = base[tid];
+            for (int wc = 0; wc < 16; ++wc) {
+                const uint32_t c = wcnt[(uint32_t)wc * (uint32_t)ntap + tid];
+                wcnt[(uint32_t)wc * (uint32_t)ntap + tid] = run;
+                run += c;
+            }
+            base[tid] = run;
         }
-        // per-tap totals over the tile
-        for (int f = 0; f < ntap; ++f) {
-            uint32_t c = (uint32_t)(st[f + 1] - st[f]);
+        __syncthreads();
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-            if (lane == 0) total[f] = c;
-        }
+        for (int u = 0; u < 4; ++u)
+            if (key[u] != 0xFFFFFFFFu)
+                ord[wcnt[((uint32_t)u * 4u + wave) * (uint32_t)ntap + key[u]] + rank[u]] = s0 + (uint32_t)u * 256u + tid;
+        __syncthreads();
     }
 }
 
+// metadata of up to kDeepBatch records of one (tile, tap) run -> LDS (thread = record: two dependent loads).
+// mqr[t] = {centre lane, bits of 1/count}; entries past the run: row 0 (never loaded), centre 64 (matches no
+// lane; row 64 of deep_dw_kernel's X tile is all zero), weight 0.
+template <bool BWD>
+__device__ __forceinline__ void deep_fetch_meta(const PairEntry *__restrict__ seg, const uint32_t *__restrict__ ord,
+                                                uint32_t e0, uint32_t e1, uint32_t *mcand, uint2 *mqr)
+{
+    const uint32_t t = threadIdx.x;
+    uint32_t cand = 0, q = 64;
+    float rcp = 0.0f;
+    if (e0 + t < e1) {
+        PairEntry en;
+        if (CONV3P_ABLATE & 4194304) { en.cand = (e0 + t) & 1023u; en.code = pair_code(0, 0, t & 63u); en.rcp_fwd = en.rcp_bwd = 1.0f; }
+        else en = seg[ord[e0 + t]];
+        cand = en.cand;
+        q = code_q(en.code);
+        rcp = BWD ? en.rcp_bwd : en.rcp_fwd;
+    }
+    mcand[t] = cand;
+    mqr[t] = make_uint2(q, __builtin_bit_cast(uint32_t, rcp));
+}
+
 // ---------------------------------------------------------------------------------------------
-// deep_gemm_kernel: out[centre, 0..NDIM) = sum_f A_f[centre, 0..KDIM) . Bm[f][KDIM][NDIM]
-//   BWD = false : forward.   src = input  (rows of KDIM = Cin),  taps = fwd, weights rcp_fwd, Bm = filter
-//   BWD = true  : grad_input. src = grad_out (rows of KDIM = Cout), taps = bwd, weights rcp_bwd, Bm = filter^T
-//                 ([F][Cout][Cin]); additionally publishes the tile's tap-major record order for deep_dw_kernel.
-// One workgroup (4 waves) per query tile.  The 2 x NDIM/32 output blocks of 32x32 are dealt to the waves
-// round-robin; accumulators stay in registers across all taps.
-// LDS: A_f [64][KDIM+1] | start [64][ntap+1] u16 | qbase [64] | qrel [64] | total [ntap] | qorig [64]
+// deep_gemm_kernel: out[centre, 0..NDIM) = sum_f M_f[centre, 0..KDIM) . Bm[f][KDIM][NDIM]
+//   BWD = false : forward.    src = input    (rows of KDIM = Cin),  order/weights of the forward taps, Bm = filter
+//   BWD = true  : grad_input. src = grad_out (rows of KDIM = Cout), backward taps, Bm = filter^T ([F][Cout][Cin])
+// One workgroup (4 waves) per query tile; per tap:
+//   stage 1  M_f = S_f . rows           32 records per block: rows copied to LDS [32][KDIM+32], the 2 x KDIM/32
+//                                        blocks of M_f dealt to the waves, accumulated in registers over the blocks
+//   stage 2  out += M_f . Bm[f]          M_f through LDS [64][KDIM+1] (aliases the row buffer), the 2 x NDIM/32
+//                                        output blocks dealt to the waves, accumulators in registers across all taps
+// LDS: { M_f [64][KDIM+1] | rows [32][KDIM+32] } | meta (cand, centre, 1/count) [256] x 3 | qorig [64]
 // ---------------------------------------------------------------------------------------------
 template <int KDIM, int NDIM, bool BWD>
-__global__ __launch_bounds__(256) void deep_gemm_kernel(const PointRec<float> *__restrict__ pts,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_WAVES))) void deep_gemm_kernel(const PointRec<float> *__restrict__ pts,
                                                         const PairEntry *__restrict__ pairs,
                                                         const uint2 *__restrict__ segs,
-                                                        const uint2 *__restrict__ qsegs,
                                                         const float *__restrict__ src,
                                                         const float *__restrict__ Bm, int N, int ntiles, int ntap,
                                                         BlockMap bm, float *__restrict__ out,
-                                                        uint16_t *__restrict__ bucket_order,
-                                                        uint32_t *__restrict__ tap_order,
-                                                        uint32_t *__restrict__ tap_off,
+                                                        const uint32_t *__restrict__ tap_order,
+                                                        const uint32_t *__restrict__ tap_off,
                                                         uint8_t *__restrict__ tile_flag)
 {
     constexpr int LDA = KDIM + 1;
-    constexpr int NBLK = 2 * (NDIM / 32);                 // 32x32 output blocks of the tile
-    constexpr int PER_WAVE = (NBLK + 3) / 4;
-    constexpr int KPL = (KDIM + 63) / 64;                 // channels per lane in the gather stage
+    constexpr int LDR = KDIM + 32;                        // half-waves read different rows: 32 banks apart
+    // 32x32 blocks of M_f (2 x KDIM/32) and of the output (2 x NDIM/32) are dealt to the 4 waves so that every
+    // index below is a compile-time constant (accumulators stay in AGPRs, no predicated MFMAs): wave w owns the
+    // row block w & 1 and the column blocks (w >> 1) + 2j.  With a single column block (32 channels) only
+    // waves 0 and 1 take part.
+    constexpr int CBK = KDIM / 32;                        // column blocks of M_f
+    constexpr int SPW = CBK >= 2 ? CBK / 2 : 1;           // ... per wave
+    constexpr int CBN = NDIM / 32;                        // column blocks of the output
+    constexpr int OPW = CBN >= 2 ? CBN / 2 : 1;
+    constexpr int F4 = KDIM / 4;                          // float4 per row
+    constexpr int RPT = (kDeepBlk * F4) / 256;            // float4 per thread and block (KDIM >= 32)
+    constexpr int KG = 8;                                 // MFMA k-steps per B-operand prefetch group
+    static_assert(KDIM % 32 == 0 && NDIM % 32 == 0 && RPT >= 1 && (CBK == 1 || CBK % 2 == 0) && (CBN == 1 || CBN % 2 == 0),
+                  "deep path: channel counts are 32 or multiples of 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *A = reinterpret_cast<float *>(smem);
-    size_t off = align16((size_t)64 * LDA * 4);
-    uint16_t *start = reinterpret_cast<uint16_t *>(smem + off);
-    off += align16((size_t)64 * (ntap + 1) * 2);
-    uint32_t *qbase = reinterpret_cast<uint32_t *>(smem + off);
-    off += 256;
-    uint32_t *qrel = reinterpret_cast<uint32_t *>(smem + off);   // start of each centre's list inside the segment
-    off += 256;
-    uint32_t *total = reinterpret_cast<uint32_t *>(smem + off);
-    off += align16((size_t)ntap * 4);
-    int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
+    float *A = reinterpret_cast<float *>(smem);           // stage 2
+    float *R = reinterpret_cast<float *>(smem);           // stage 1 (same bytes)
+    constexpr size_t kUnion = (size_t)64 * LDA * 4 > (size_t)kDeepBlk * LDR * 4 ? (size_t)64 * LDA * 4 : (size_t)kDeepBlk * LDR * 4;
+    size_t off = align16(kUnion);
+    uint2 *mqr = reinterpret_cast<uint2 *>(smem + off);
+    uint32_t *mcand = reinterpret_cast<uint32_t *>(mqr + kDeepBatch);
+    int32_t *qorig = reinterpret_cast<int32_t *>(mcand + kDeepBatch);
 
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rb = wave & 1, cb0 = wave >> 1;             // this wave's row block and first column block
+    const bool s_on = CBK >= 2 || wave < 2, o_on = CBN >= 2 || wave < 2;
+    const uint32_t myrow = (uint32_t)(rb * 32 + (lane & 31));
     const size_t tile_id = (size_t)b * ntiles + qt;
-    const uint2 tseg = segs[tile_id];                      // ngroups == 1 on this path (host checks)
+    const uint2 tseg = segs[tile_id];
     if (wave == 0) qorig[lane] = pts[tile_id * kTile + lane].idx;
+    float *out_cloud = out + (size_t)b * N * NDIM;
     if (tseg.y == kSegOverflow) {
-        // the cloud's pair region overflowed: leave zero rows and flag the tile; the generic kernel is launched
-        // afterwards for flagged tiles only (it can search the tile itself)
-        if (threadIdx.x == 0) tile_flag[tile_id] = 1;
+        // the cloud's pair region overflowed: leave zero rows; the generic kernel is launched afterwards for the
+        // tiles deep_order_kernel flagged (it can search the tile itself)
         __syncthreads();
-        float *oc = out + (size_t)b * N * NDIM;
         for (int e = threadIdx.x; e < 64 * NDIM; e += 256) {
             const int orig = qorig[e / NDIM];
-            if (orig >= 0) oc[(size_t)orig * NDIM + (e % NDIM)] = 0.0f;
-        }
-        if (BWD && threadIdx.x == 0) {
-            uint32_t *toff = tap_off + tile_id * (ntap + 1);
-            for (int f = 0; f <= ntap; ++f) toff[f] = 0;    // deep_dw_kernel skips the tile
+            if (orig >= 0) out_cloud[(size_t)orig * NDIM + (e % NDIM)] = 0.0f;
         }
         return;
     }
     const PairEntry *seg = pairs + tseg.x;
-    uint16_t *order = bucket_order + tseg.x;               // this tile's share of the global scratch
-    if (threadIdx.x == 0) tile_flag[tile_id] = 0;
-    if (wave == 0) qrel[lane] = qsegs[tile_id * 64 + lane].x - tseg.x;
-    bucket_by_tap<BWD>(seg, qsegs + tile_id * 64, tseg.x, ntap, start, order, qbase, total);
-    __syncthreads();
+    const uint32_t *ord = tap_order + tseg.x;
+    const uint32_t *toff = tap_off + tile_id * (size_t)(ntap + 1);
+    const float *src_cloud = src + (size_t)b * N * KDIM;
 
-    if (BWD) {
-        // tap-major order of the tile's records (tap ascending, centre ascending, list order) for deep_dw_kernel:
-        // tap_order[slot] = record index relative to the tile's segment
-        uint32_t *toff = tap_off + tile_id * (ntap + 1);
-        if (wave == 0) {
-            uint32_t run = 0;
-            for (int f = 0; f < ntap; ++f) {
-                const uint32_t c = (uint32_t)(start[lane * (ntap + 1) + f + 1] - start[lane * (ntap + 1) + f]);
-                int tot;
-                const uint32_t pos = run + (uint32_t)wave_excl_scan((int)c, tot);
-                const uint32_t from = qbase[lane] + start[lane * (ntap + 1) + f];
-                for (uint32_t p = 0; p < c; ++p) tap_order[tseg.x + pos + p] = qrel[lane] + order[from + p];
-                if (lane == 0) toff[f] = run;
-                run += (uint32_t)tot;
-            }
-            if (lane == 0) toff[ntap] = run;
-        }
-    }
-
-    f32x16 acc[PER_WAVE];
+    f32x16 acc[OPW];
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i)
+    for (int i = 0; i < OPW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    const float *src_cloud = src + (size_t)b * N * KDIM;
+    // rows of one block -> registers (float4 per thread: row = e / F4, column = 4 * (e % F4)); rows past the
+    // batch's last record are zero.  S_f multiplies every staged row by 0 for the centres it does not belong to,
+    // which is only harmless for finite values: a non-finite row sends the whole tile to the exact generic
+    // kernel instead (tile_flag), so that NaN / Inf reach exactly the outputs they reach in the reference.
+    float badsum = 0.0f;
+    auto load_rows = [&](uint32_t p0, uint32_t nrec, float4 (&rv)[RPT]) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int e = (int)threadIdx.x + 256 * u;
+            const uint32_t p = p0 + (uint32_t)(e / F4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < nrec) v = *reinterpret_cast<const float4 *>(src_cloud + (size_t)mcand[p] * KDIM + 4 * (e % F4));
+            rv[u] = v;                                   // nothing here may consume v: the loads stay in flight
+        }
+    };
+    auto store_rows = [&](const float4 (&rv)[RPT]) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int e = (int)threadIdx.x + 256 * u;
+            const float4 v = rv[u];
+            badsum += ((v.x - v.x) + (v.y - v.y)) + ((v.z - v.z) + (v.w - v.w));   // 0 for finite values, NaN otherwise
+            *reinterpret_cast<float4 *>(R + (e / F4) * LDR + 4 * (e % F4)) = v;
+        }
+    };
+
     for (int f = 0; f < ntap; ++f) {
-        if (total[f] == 0) continue;                        // block-uniform
-        // ---- gather-reduce: A[q][:] = sum of the tap-f neighbour rows of centre q, normalised
-        for (int q = wave; q < 64; q += 4) {
-            const uint32_t r0 = start[q * (ntap + 1) + f], r1 = start[q * (ntap + 1) + f + 1];
-            float av[KPL];
+        const uint32_t e0 = toff[f], e1 = toff[f + 1];
+        if (e0 == e1) continue;                              // block-uniform
+        // ---- stage 1: M_f = S_f . rows
+        f32x16 am[SPW];
 #pragma unroll
-            for (int u = 0; u < KPL; ++u) av[u] = 0.0f;
-            for (uint32_t p0 = r0; p0 < r1; p0 += 64) {
-                // lanes fetch (neighbour, weight) of up to 64 records in parallel: one latency, not one per record
-                uint32_t mcand = 0;
-                float mw = 0.0f;
-                if (p0 + lane < r1) {
-                    const PairEntry en = seg[qrel[q] + order[qbase[q] + p0 + lane]];
-                    mcand = en.cand;
-                    mw = BWD ? en.rcp_bwd : en.rcp_fwd;
-                }
-                const int nrec = (int)min(64u, r1 - p0);
-                for (int r = 0; r < nrec; r += 4) {
-                    // four independent row loads in flight
-                    float rv[4][KPL], wv[4];
+        for (int j = 0; j < SPW; ++j)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int rr = r + t < nrec ? r + t : r;
-                        const uint32_t cand = __shfl(mcand, rr);
-                        wv[t] = r + t < nrec ? __shfl(mw, rr) : 0.0f;
-                        const float *row = src_cloud + (size_t)cand * KDIM;
+            for (int r = 0; r < 16; ++r) am[j][r] = 0.0f;
+        for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
+            __syncthreads();                                 // meta / LDS union free
+            deep_fetch_meta<BWD>(seg, ord, eb, e1, mcand, mqr);
+            __syncthreads();
+            const uint32_t nrec = min((uint32_t)kDeepBatch, e1 - eb);
+            float4 rv[RPT];
+            load_rows(0, nrec, rv);
+            for (uint32_t p0 = 0; p0 < nrec; p0 += kDeepBlk) {
+                store_rows(rv);
+                __syncthreads();
+                if (p0 + kDeepBlk < nrec) load_rows(p0 + kDeepBlk, nrec, rv);   // in flight under the MFMAs below
+                if (s_on && !(CONV3P_ABLATE & 32768)) {
+                    // always the block's 16 k-steps (rows past the last record are zero, their weight is 0):
+                    // straight-line code, every LDS operand of a group of 4 steps in flight before its MFMAs
+                    const float *rrow = R + (lane >> 5) * LDR + cb0 * 32 + (lane & 31);
+                    const uint2 *mrow = mqr + p0 + (uint32_t)(lane >> 5);
 #pragma unroll
-                        for (int u = 0; u < KPL; ++u) rv[t][u] = lane + 64 * u < KDIM ? row[lane + 64 * u] : 0.0f;
+                    for (int s4 = 0; s4 < kDeepBlk / 2; s4 += 4) {
+                        uint2 m[4];
+                        float bv[4][SPW];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            m[t] = mrow[2 * (s4 + t)];
+#pragma unroll
+                            for (int j = 0; j < SPW; ++j) bv[t][j] = rrow[2 * (s4 + t) * LDR + j * 64];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            // S_f operand: 1/count where the record belongs to this lane's centre, else 0
+                            const float sv = m[t].x == myrow ? __builtin_bit_cast(float, m[t].y) : 0.0f;
+#pragma unroll
+                            for (int j = 0; j < SPW; ++j)
+                                am[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, bv[t][j], am[j], 0, 0, 0);
+                        }
                     }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int u = 0; u < KPL; ++u) av[u] = __builtin_fmaf(rv[t][u], wv[t], av[u]);
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < KPL; ++u)
-                if (lane + 64 * u < KDIM) A[q * LDA + lane + 64 * u] = av[u];
-        }
-        __syncthreads();
-        // ---- [64 x KDIM] . [KDIM x NDIM] on the matrix cores
-        const float *Bf = Bm + (size_t)f * KDIM * NDIM;
-        for (int k0 = 0; k0 < KDIM; k0 += 2) {
-            const int kk = k0 + (lane >> 5);
-            const float a0 = A[(lane & 31) * LDA + kk];
-            const float a1 = A[(32 + (lane & 31)) * LDA + kk];
-#pragma unroll
-            for (int i = 0; i < PER_WAVE; ++i) {
-                const int blk = wave + 4 * i;                // block id = rb * (NDIM/32) + cb
-                if (blk < NBLK) {
-                    const int rb = blk / (NDIM / 32), cb = blk % (NDIM / 32);
-                    const float bv = Bf[(size_t)kk * NDIM + cb * 32 + (lane & 31)];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb ? a1 : a0, bv, acc[i], 0, 0, 0);
-                }
+                __syncthreads();                             // rows consumed
             }
         }
+        // M_f fragments -> LDS [64][LDA]
+        if (s_on) {
+#pragma unroll
+            for (int j = 0; j < SPW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    A[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDA + (cb0 + 2 * j) * 32 + (lane & 31)] = am[j][r];
+        }
         __syncthreads();
+        // ---- stage 2: out += M_f . Bm[f]   (B operand from L2, one group of KG k-steps ahead)
+        if (o_on) {
+            const float *Bf = Bm + (size_t)f * KDIM * NDIM + (lane >> 5) * NDIM + cb0 * 32 + (lane & 31);
+            const float *arow = A + myrow * LDA + (lane >> 5);
+            float bc[KG][OPW], bn[KG][OPW];
+            auto load_b = [&](int k0, float (&bv)[KG][OPW]) {
+#pragma unroll
+                for (int s = 0; s < KG; ++s)
+#pragma unroll
+                    for (int j = 0; j < OPW; ++j) bv[s][j] = Bf[(size_t)(k0 + 2 * s) * NDIM + j * 64];
+            };
+            load_b(0, bc);
+            for (int k0 = 0; k0 < ((CONV3P_ABLATE & 65536) ? 0 : KDIM); k0 += 2 * KG) {
+                if (k0 + 2 * KG < KDIM) load_b(k0 + 2 * KG, bn);
+#pragma unroll
+                for (int s = 0; s < KG; ++s) {
+                    const float a = arow[k0 + 2 * s];
+#pragma unroll
+                    for (int j = 0; j < OPW; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[s][j], acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < KG; ++s)
+#pragma unroll
+                    for (int j = 0; j < OPW; ++j) bc[s][j] = bn[s][j];
+            }
+        }
     }
 
-    // ---- epilogue: C fragment -> out rows (by original index)
-    float *out_cloud = out + (size_t)b * N * NDIM;
+    // ---- epilogue: C fragments -> out rows (by original index)
+    const bool bad = __syncthreads_or(!(badsum == 0.0f)) != 0;
+    if (bad && threadIdx.x == 0) tile_flag[tile_id] = 1;   // zero rows now, exact accumulation by the generic kernel
+    if (o_on) {
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int blk = wave + 4 * i;
-        if (blk < NBLK) {
-            const int rb = blk / (NDIM / 32), cb = blk % (NDIM / 32);
+        for (int j = 0; j < OPW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int orig = qorig[row];
-                if (orig >= 0) out_cloud[(size_t)orig * NDIM + cb * 32 + (lane & 31)] = acc[i][r];
+                if (orig >= 0) out_cloud[(size_t)orig * NDIM + (cb0 + 2 * j) * 32 + (lane & 31)] = bad ? 0.0f : acc[j][r];
             }
-        }
     }
 }
 
+// Launch order of the taps in deep_dw_kernel.  A tap's workgroups cost in proportion to its number of pairs, and
+// on surface-like clouds the central tap holds ~3x the average, the corner taps far less: the (tap, chunk) grid
+// is issued with the taps nearest to the stencil centre first, so that the long workgroups start first and the
+// short ones fill in behind them.
+struct TapPerm {
+    uint8_t t[64];
+};
+
 // ---------------------------------------------------------------------------------------------
-// deep_dw_kernel: grad_filter partials.  Workgroup = (tap f, 64-column slice of Cout, chunk of query tiles):
-//   dW[f][0..CIN)[n0..n0+64) = sum over the chunk's tiles of  X_tile^T [CIN x 64] . G_f [64 x 64]
-// G_f (this tap, this column slice) is gather-reduced per tile from the tap-major record order written by
-// deep_gemm_kernel<.., BWD=true>.  Wave w owns the row blocks w, w+4, ... of CIN; accumulators live in
-// registers across the whole chunk; one partial per chunk, summed by reduce_partials_kernel.
-// LDS: X tile [64][CIN+1] | G [64][65]
+// deep_dw_kernel: grad_filter partials.  Workgroup = (backward tap f, chunk of query tiles):
+//   dW[f][0..CIN)[0..COUT) = sum over the chunk's records of tap f:  x[centre]^T (CIN x 1) . dY[neighbour] / count
+// i.e. a [CIN x P].[P x COUT] GEMM whose k dimension is the record index: per tile the X tile is in LDS (the A
+// operand of record p is row `centre(p)` of it), the dY rows of 32 records at a time are copied into LDS already
+// multiplied by 1/count (the next block's loads in flight under the MFMAs).  The waves form a WM x WN grid over
+// the CIN/32 x COUT/32 output blocks; accumulators stay in registers over the whole chunk; one partial per
+// chunk, summed by reduce_partials_kernel in fixed order.
+// LDS: X tile [64][CIN+1] | rows [32][COUT+32] | meta [256] x 3 | qorig [64]
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void deep_dw_kernel(const PointRec<float> *__restrict__ pts,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void deep_dw_kernel(const PointRec<float> *__restrict__ pts,
                                                       const PairEntry *__restrict__ pairs,
                                                       const uint2 *__restrict__ segs,
                                                       const uint32_t *__restrict__ tap_order,
                                                       const uint32_t *__restrict__ tap_off,
                                                       const float *__restrict__ grad_out,
                                                       const float *__restrict__ input, int B, int N, int ntiles,
-                                                      int ntap, int nchunks, float *__restrict__ partials)
+                                                      int ntap, int nchunks, const uint8_t *__restrict__ tile_flag,
+                                                      TapPerm tapperm, float *__restrict__ partials)
 {
     constexpr int LDX = CIN + 1;
-    constexpr int RB = CIN / 32;                           // row blocks of CIN
-    constexpr int PER_WAVE = (RB + 3) / 4;
+    constexpr int LDR = COUT + 32;
+    constexpr int MB = CIN / 32, NB = COUT / 32;
+    constexpr int WN = NB >= 4 ? 4 : NB, WM = 4 / WN;      // wave grid
+    constexpr int PM = (MB + WM - 1) / WM, PN = NB / WN;   // blocks per wave along each axis
+    static_assert(NB % WN == 0 && (MB % WM == 0 || MB < WM), "deep path: channel counts are 32 or multiples of 64");
+    constexpr int F4 = COUT / 4;
+    constexpr int RPT = (kDeepBlk * F4) / 256;
+    static_assert(CIN % 32 == 0 && COUT % 32 == 0 && RPT >= 1, "deep path: channel counts are multiples of 32");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *X = reinterpret_cast<float *>(smem);
-    float *G = reinterpret_cast<float *>(smem + align16((size_t)64 * LDX * 4));
-    __shared__ int32_t qorig[64];
-    __shared__ uint32_t mcand[256], mq[256];
-    __shared__ float mrcp[256];
+    float *X = reinterpret_cast<float *>(smem);          // [65][LDX]: row 64 stays zero (padding records)
+    size_t off = align16((size_t)65 * LDX * 4);
+    float *R = reinterpret_cast<float *>(smem + off);
+    off += align16((size_t)kDeepBlk * LDR * 4);
+    uint2 *mqr = reinterpret_cast<uint2 *>(smem + off);
+    uint32_t *mcand = reinterpret_cast<uint32_t *>(mqr + kDeepBatch);
+    int32_t *qorig = reinterpret_cast<int32_t *>(mcand + kDeepBatch);
+    for (int e = threadIdx.x; e < LDX; e += 256) X[64 * LDX + e] = 0.0f;
 
-    const int f = blockIdx.x, slice = blockIdx.y, chunk = blockIdx.z;
-    const int n0 = slice * 64;
+    const int f = tapperm.t[blockIdx.x], chunk = blockIdx.y;   // taps fastest: the 27 workgroups of a chunk share its rows in L2
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    f32x16 acc[PER_WAVE][2];
+    const int wm = wave / WN, wn = wave % WN;
+    const bool w_on = MB % WM == 0 || wm < MB;             // (32-channel inputs: only the first row of waves)
+    f32x16 acc[PM][PN];
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i)
+    for (int i = 0; i < PM; ++i)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int j = 0; j < PN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const size_t total_tiles = (size_t)B * ntiles;
     const size_t per = (total_tiles + nchunks - 1) / nchunks;
     const size_t t0 = per * chunk, t1 = (t0 + per < total_tiles) ? t0 + per : total_tiles;
+#if CONV3P_ABLATE & 16777216
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    long long nblk_dbg = 0, ntile_dbg = 0;
+#define DBG_T(i) { const long long t_ = wall_clock64(); tk[i] += t_ - tlast; tlast = t_; }
+    long long tlast = wall_clock64();
+#else
+#define DBG_T(i)
+#endif
     for (size_t tile = t0; tile < t1; ++tile) {
-        const uint32_t *toff = tap_off + tile * (ntap + 1);
+        const uint32_t *toff = tap_off + tile * (size_t)(ntap + 1);
         const uint32_t e0 = toff[f], e1 = toff[f + 1];
-        if (e0 == e1) continue;                             // uniform: no neighbour with this tap in the tile
+        if (e0 == e1 || tile_flag[tile]) continue;          // uniform: nothing with this tap / generic kernel's tile
         const int b = (int)(tile / ntiles);
         const uint2 tseg = segs[tile];
         const PairEntry *seg = pairs + tseg.x;
         const uint32_t *ord = tap_order + tseg.x;
-        if (wave == 0) qorig[lane] = pts[tile * kTile + lane].idx;
-        for (int e = threadIdx.x; e < 64 * 65; e += 256) G[e] = 0.0f;
-        __syncthreads();
-        // X tile (rows by original index; padding centres -> 0)
-        for (int q = wave; q < 64; q += 4) {
-            const int orig = qorig[q];
-            const float *xr = input + ((size_t)b * N + (orig < 0 ? 0 : orig)) * CIN;
-            for (int k = lane; k < CIN; k += 64) X[q * LDX + k] = orig >= 0 ? xr[k] : 0.0f;
-        }
-        // G[q][0..64) += dY[cand][n0..n0+64) / count   (records of a centre are consecutive; wave = q & 3 owns it)
         const float *dy_cloud = grad_out + (size_t)b * N * COUT;
-        for (uint32_t eb = e0; eb < e1; eb += 256) {
-            // 256 threads fetch the metadata of up to 256 records in parallel, then every wave walks them
-            __syncthreads();
-            if (eb + threadIdx.x < e1) {
-                const PairEntry en = seg[ord[eb + threadIdx.x]];
-                mcand[threadIdx.x] = en.cand;
-                mq[threadIdx.x] = code_q(en.code);
-                mrcp[threadIdx.x] = en.rcp_bwd;
-            }
-            __syncthreads();
-            const int nrec = (int)min(256u, e1 - eb);
-            for (int r = 0; r < nrec; ++r) {
-                const uint32_t q = mq[r];
-                if ((int)(q & 3) == wave)
-                    G[q * 65 + lane] += dy_cloud[(size_t)mcand[r] * COUT + n0 + lane] * mrcp[r];
-            }
-        }
+        DBG_T(0)
+        __syncthreads();                                    // previous tile's X / rows consumed
+        if (wave == 0) qorig[lane] = pts[tile * kTile + lane].idx;
+        deep_fetch_meta<true>(seg, ord, e0, e1, mcand, mqr);
         __syncthreads();
-        // X^T [CIN x 64] . G [64 x 64]
-        for (int k0 = 0; k0 < 64; k0 += 2) {
-            const int kk = k0 + (lane >> 5);
-            const float b0 = G[kk * 65 + (lane & 31)], b1 = G[kk * 65 + 32 + (lane & 31)];
+        DBG_T(1)
+        // X tile (rows by original index; padding centres -> 0): all of a thread's float4 loads in flight together
+        {
+            constexpr int XPT = (64 * (CIN / 4)) / 256;      // float4 per thread (CIN >= 32)
+            float4 xv[XPT];
 #pragma unroll
-            for (int i = 0; i < PER_WAVE; ++i) {
-                const int rb = wave + 4 * i;
-                if (rb < RB) {
-                    const float a = X[kk * LDX + rb * 32 + (lane & 31)];
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[i][1], 0, 0, 0);
-                }
+            for (int u = 0; u < XPT; ++u) {
+                const int e = (int)threadIdx.x + 256 * u;
+                const int orig = qorig[e / (CIN / 4)];
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (orig >= 0 && !(CONV3P_ABLATE & 2097152))
+                    xv[u] = *reinterpret_cast<const float4 *>(input + ((size_t)b * N + orig) * CIN + 4 * (e % (CIN / 4)));
+            }
+#pragma unroll
+            for (int u = 0; u < XPT; ++u) {
+                const int e = (int)threadIdx.x + 256 * u;
+                float *xr = X + (e / (CIN / 4)) * LDX + 4 * (e % (CIN / 4));
+                xr[0] = xv[u].x; xr[1] = xv[u].y; xr[2] = xv[u].z; xr[3] = xv[u].w;
             }
         }
-        __syncthreads();
+        auto load_rows = [&](uint32_t p0, uint32_t nrec, float4 (&rv)[RPT]) {
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                const int e = (int)threadIdx.x + 256 * u;
+                const uint32_t p = p0 + (uint32_t)(e / F4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // rows past the last record contribute nothing
+                if (p < nrec) v = *reinterpret_cast<const float4 *>(dy_cloud + (size_t)mcand[p] * COUT + 4 * (e % F4));
+                rv[u] = v;                               // nothing here may consume v: the loads stay in flight
+            }
+        };
+        auto store_rows = [&](uint32_t p0, const float4 (&rv)[RPT]) {
+#pragma unroll
+            for (int u = 0; u < RPT; ++u) {
+                const int e = (int)threadIdx.x + 256 * u;
+                const float w = __builtin_bit_cast(float, mqr[p0 + (uint32_t)(e / F4)].y);   // dY / count (.cpp:692, :696)
+                float4 v = rv[u];
+                v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+                *reinterpret_cast<float4 *>(R + (e / F4) * LDR + 4 * (e % F4)) = v;
+            }
+        };
+        for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
+            if (eb != e0) {
+                __syncthreads();
+                deep_fetch_meta<true>(seg, ord, eb, e1, mcand, mqr);
+                __syncthreads();
+            }
+            const uint32_t nrec = min((uint32_t)kDeepBatch, e1 - eb);
+            float4 rv[RPT];
+            load_rows(0, nrec, rv);
+            DBG_T(2)
+            for (uint32_t p0 = 0; p0 < nrec; p0 += kDeepBlk) {
+                if (!(CONV3P_ABLATE & 1048576)) store_rows(p0, rv);
+                if (!(CONV3P_ABLATE & 524288)) __syncthreads();                            // rows (and, first time, the X tile) visible
+                DBG_T(3)
+                if (!(CONV3P_ABLATE & 1048576) && p0 + kDeepBlk < nrec) load_rows(p0 + kDeepBlk, nrec, rv);
+                if (w_on && !(CONV3P_ABLATE & 131072)) {
+                    // always the block's 16 k-steps (rows past the last record are zero and pair with the zero
+                    // row 64 of X): straight-line code, a group's LDS operands in flight before its MFMAs
+                    const float *rbase = R + (lane >> 5) * LDR + wn * 32 + (lane & 31);
+                    const uint2 *mrow = mqr + p0 + (uint32_t)(lane >> 5);
+#pragma unroll
+                    for (int s2 = 0; s2 < kDeepBlk / 2; s2 += 2) {
+                        float a[2][PM], bv[2][PN];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const float *xrow = X + mrow[2 * (s2 + t)].x * LDX + wm * 32 + (lane & 31);
+#pragma unroll
+                            for (int i = 0; i < PM; ++i) a[t][i] = (CONV3P_ABLATE & 262144) ? (float)(i + lane) : xrow[i * WM * 32];
+#pragma unroll
+                            for (int j = 0; j < PN; ++j) bv[t][j] = (CONV3P_ABLATE & 262144) ? (float)(j - lane) : rbase[2 * (s2 + t) * LDR + j * WN * 32];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int i = 0; i < PM; ++i)
+#pragma unroll
+                                for (int j = 0; j < PN; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][i], bv[t][j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                DBG_T(4)
+                if (!(CONV3P_ABLATE & 524288)) __syncthreads();                            // rows consumed
+                DBG_T(5)
+#if CONV3P_ABLATE & 16777216
+                nblk_dbg++;
+#endif
+            }
+        }
+#if CONV3P_ABLATE & 16777216
+        ntile_dbg++;
+#endif
     }
+#if CONV3P_ABLATE & 16777216
+    if (threadIdx.x == 0 && f == 13 && blockIdx.y == 1)
+        printf("dw dbg (100 MHz ticks): tiles %lld blocks %lld | loop-head %lld  meta %lld  X+rows0 %lld  store+sync %lld  loads+mfma %lld  sync2 %lld\n",
+               ntile_dbg, nblk_dbg, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
+#endif
 
     // partial slot of this chunk: layout of grad_filter, [(f*CIN + k)*COUT + c]
     float *slot = partials + (size_t)chunk * ntap * CIN * COUT + (size_t)f * CIN * COUT;
+    if (w_on) {
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int rb = wave + 4 * i;
-        if (rb < RB)
+        for (int i = 0; i < PM; ++i)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < PN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int k = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    slot[(size_t)k * COUT + n0 + c * 32 + (lane & 31)] = acc[i][c][r];
+                    const int k = (wm + WM * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    slot[(size_t)k * COUT + (wn + WN * j) * 32 + (lane & 31)] = acc[i][j][r];
                 }
     }
 }
