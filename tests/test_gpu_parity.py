@@ -533,3 +533,28 @@ def test_cloud_larger_than_the_lds_sort(dev):
     ref = (oracle.neighbor_count(P, (3, 3, 3), s, VOX), oracle.forward(P, X, W, s, VOX, nthreads=8)) + \
         oracle.backward(dY, P, X, W, s, VOX, nthreads=1)
     check_against(ref, run_hip(dev, P, X, W, dY, s), np.float32)
+
+
+def test_deep_channel_path_non_finite_values_reach_only_their_neighbours(dev):
+    """The matrix-core path multiplies staged neighbour rows by 0 for the centres they do not belong to, which is
+    only exact for finite rows: tiles that meet an Inf / NaN row are handed to the exact generic kernel, so the
+    non-finite values land on exactly the outputs they reach in the reference."""
+    B, N, ci, co = 1, 300, 32, 64
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=1040)
+    X = X.copy(); dY = dY.copy()
+    X[0, 17, 3] = np.inf
+    X[0, 200, 0] = np.nan
+    dY[0, 99, 5] = np.inf
+    s = (1, 1, 1)
+    with np.errstate(all="ignore"):
+        y_ref = oracle.forward(P, X, W, s, VOX)
+        dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, VOX)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    y = op.conv3p(t(P), t(X), t(W), s, VOX).cpu().numpy()
+    dx, dw = op.conv3p_grad(t(dY), t(P), t(X), t(W), s, VOX)
+    for got, ref, tol in ((y, y_ref, 1e-5), (dx.cpu().numpy(), dx_ref, 1e-5), (dw.cpu().numpy(), dw_ref, 2e-5)):
+        bad_ref = ~np.isfinite(ref)
+        assert bad_ref.any() and not bad_ref.all()
+        assert np.array_equal(~np.isfinite(got), bad_ref)
+        ok = ~bad_ref
+        assert np.max(np.abs(got[ok] - ref[ok])) <= tol * max(1.0, np.max(np.abs(ref[ok])))
