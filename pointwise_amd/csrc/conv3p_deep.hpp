@@ -253,6 +253,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
         }
     };
 
+#if CONV3P_ABLATE & 16777216
+    long long gk[6] = {0, 0, 0, 0, 0, 0};
+    long long gblk = 0, gtap = 0;
+#define GDBG(i) { const long long t_ = wall_clock64(); gk[i] += t_ - glast; glast = t_; }
+    long long glast = wall_clock64();
+#else
+#define GDBG(i)
+#endif
     for (int f = 0; f < ntap; ++f) {
         const uint32_t e0 = toff[f], e1 = toff[f + 1];
         if (e0 == e1) continue;                              // block-uniform
@@ -266,12 +274,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             __syncthreads();                                 // meta / LDS union free
             deep_fetch_meta<BWD>(seg, ord, eb, e1, mcand, mqr);
             __syncthreads();
+            GDBG(0)
             const uint32_t nrec = min((uint32_t)kDeepBatch, e1 - eb);
             float4 rv[RPT];
             load_rows(0, nrec, rv);
             for (uint32_t p0 = 0; p0 < nrec; p0 += kDeepBlk) {
                 store_rows(rv);
                 __syncthreads();
+                GDBG(1)
                 if (p0 + kDeepBlk < nrec) load_rows(p0 + kDeepBlk, nrec, rv);   // in flight under the MFMAs below
                 if (s_on && !(CONV3P_ABLATE & 32768)) {
                     // always the block's 16 k-steps (rows past the last record are zero, their weight is 0):
@@ -298,9 +308,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                         }
                     }
                 }
+                GDBG(2)
                 __syncthreads();                             // rows consumed
+                GDBG(3)
+#if CONV3P_ABLATE & 16777216
+                gblk++;
+#endif
             }
         }
+#if CONV3P_ABLATE & 16777216
+        gtap++;
+#endif
         // M_f fragments -> LDS [64][LDA]
         if (s_on) {
 #pragma unroll
@@ -310,6 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                     A[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDA + (cb0 + 2 * j) * 32 + (lane & 31)] = am[j][r];
         }
         __syncthreads();
+        GDBG(4)
         // ---- stage 2: out += M_f . Bm[f]   (B operand from L2, one group of KG k-steps ahead)
         if (o_on) {
             const float *Bf = Bm + (size_t)f * KDIM * NDIM + (lane >> 5) * NDIM + cb0 * 32 + (lane & 31);
@@ -339,6 +358,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
         }
     }
 
+    GDBG(5)
+#if CONV3P_ABLATE & 16777216
+    if (threadIdx.x == 0 && (blockIdx.x % 400) == 100)   // developer instrumentation build only
+        printf("gemm<%d,%d,%d> dbg (10 ns ticks): taps %lld blocks %lld | meta %lld  store+sync %lld  s1-mfma %lld  sync %lld  Mf->LDS %lld  stage2(+last) %lld\n",
+               KDIM, NDIM, (int)BWD, gtap, gblk, gk[0], gk[1], gk[2], gk[3], gk[4], gk[5]);
+#endif
     // ---- epilogue: C fragments -> out rows (by original index)
     const bool bad = __syncthreads_or(!(badsum == 0.0f)) != 0;
     if (bad && threadIdx.x == 0) tile_flag[tile_id] = 1;   // zero rows now, exact accumulation by the generic kernel
