@@ -24,5 +24,11 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LD
   python $ROOT/tools/pmc_query.py $OUT/${TAG}_pmc_$N/p_results.db conv3p > $OUT/${TAG}_pmc_$N.txt 2>&1
 done
 python $ROOT/tools/traffic_json.py $OUT/${TAG}_pmc_FETCH_SIZE/p_results.db $OUT/${TAG}_pmc_WRITE_SIZE/p_results.db > $OUT/${TAG}_traffic.json
-rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_*/   # keep the text summaries, drop the databases
+# 4. deep-channel path (cfg5 per-GPU shard: B=16, N=8192, 128->256): parity + timing, kernel summary, MFMA counters
+python $ROOT/tools/deep_check.py > $OUT/${TAG}_deep_check.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_deep_trace -o t -- python $ROOT/tools/deep_time.py > $OUT/${TAG}_deep_trace.log 2>&1
+python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_trace/t_results.db deep > $OUT/${TAG}_deep_kernel_stats.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_deep_pmc -o p -- python $ROOT/tools/deep_time.py > $OUT/${TAG}_deep_pmc.log 2>&1
+python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_pmc/p_results.db deep > $OUT/${TAG}_deep_pmc_MFMA.txt 2>&1
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_*/ $OUT/${TAG}_deep_trace $OUT/${TAG}_deep_pmc   # keep the text summaries, drop the databases
 tail -c 1500 $OUT/${TAG}_bench.json; echo; head -14 $OUT/${TAG}_kernel_stats.txt; cat $OUT/${TAG}_traffic.json

@@ -1,7 +1,7 @@
 """Developer check of the deep-channel (matrix-core) path: which kernels ran, parity vs the oracle, timing."""
 import ctypes, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
 from oracle import oracle
 from pointwise_amd import _lib, conv3p_op as op, synth
 from tests.parity_util import rel_err
