@@ -432,6 +432,8 @@ struct DeepScratch {   // carved from the per-call scratch region
     uint32_t *tap_order;   // per pair slot: tile tap-major record order
     uint32_t *tap_off;     // [tiles][F+1]
     uint8_t *tile_flag;    // [tiles]
+    uint32_t *sched;       // [8][sched_cap] launch order of the tiles per XCD (deep_sched_kernel)
+    int sched_cap;
     float *partials;       // [nchunks + 1][F*Cin*Cout]
     int nchunks;
     size_t bytes;
@@ -458,6 +460,8 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     s.tap_order = reinterpret_cast<uint32_t *>(take(pair_slots * 4));
     s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
+    s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
+    s.sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
     s.partials = reinterpret_cast<float *>(take(nw * 4 * (size_t)(s.nchunks + 1)));
     s.bytes = off;
     return s;
@@ -474,6 +478,7 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     Scope sc(K_DEEP_ORDER, c.s);
     hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, S.pairs, S.segs,
                        d.ntap, ds.tap_order, ds.tap_off, ds.tile_flag);
+    hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, S.segs, d.B, d.ntiles, ds.sched_cap, ds.sched);
     return hip_ok();
 }
 
@@ -490,7 +495,8 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_gemm_kernel<KD, ND, BWD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((deep_gemm_kernel<KD, ND, BWD>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs,
-                       S.segs, src, Bm, d.N, d.ntiles, d.ntap, bm, out, ds.tap_order, ds.tap_off, ds.tile_flag);
+                       S.segs, src, Bm, d.N, d.ntiles, d.ntap, ds.sched, ds.sched_cap, out, ds.tap_order, ds.tap_off,
+                       ds.tile_flag);
     return hip_ok();
 }
 

@@ -129,6 +129,55 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// deep_sched_kernel: launch order of the query tiles for deep_gemm_kernel.  A tile's cost grows with its number
+// of records (boundary tiles of a cloud hold a fraction of an interior tile's), and the kernel runs ~4 rounds of
+// long workgroups, so the tiles of every XCD (clouds stay on their XCD, see BlockMap) are issued longest first:
+// sched[xcd * cap + i] = i-th tile (b * ntiles + qt) of that XCD, 0xFFFFFFFF past its last one.
+// One workgroup per XCD; bitonic sort of (records descending, tile id ascending) keys in LDS, up to 4096 tiles per
+// XCD (more: the BlockMap order is kept).
+// ---------------------------------------------------------------------------------------------
+constexpr int kSchedMax = 4096;
+__global__ __launch_bounds__(1024) void deep_sched_kernel(const uint2 *__restrict__ segs, int B, int ntiles, int cap,
+                                                          uint32_t *__restrict__ sched)
+{
+    __shared__ unsigned long long keys[kSchedMax];
+    const int xcd = blockIdx.x;
+    const int nclouds = B > xcd ? (B - xcd + 7) / 8 : 0;
+    const int n = nclouds * ntiles;
+    uint32_t *out = sched + (size_t)xcd * cap;
+    if (n > kSchedMax) {
+        for (int i = threadIdx.x; i < cap; i += blockDim.x)
+            out[i] = i < n ? (uint32_t)((xcd + 8 * (i / ntiles)) * ntiles + i % ntiles) : 0xFFFFFFFFu;
+        return;
+    }
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        unsigned long long k = ~0ull;                        // padding sorts last
+        if (i < n) {
+            const uint32_t tile = (uint32_t)((xcd + 8 * (i / ntiles)) * ntiles + i % ntiles);
+            const uint32_t recs = segs[tile].y == kSegOverflow ? 0u : segs[tile].y;
+            k = ((unsigned long long)(0xFFFFFFFFu - recs) << 32) | tile;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < npad; t += blockDim.x) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const unsigned long long a = keys[t], b = keys[p];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { keys[t] = b; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) out[i] = i < n ? (uint32_t)keys[i] : 0xFFFFFFFFu;
+}
+
 // metadata of up to kDeepBatch records of one (tile, tap) run -> LDS (thread = record: two dependent loads).
 // mqr[t] = {centre lane, bits of 1/count}; entries past the run: row 0 (never loaded), centre 64 (matches no
 // lane; row 64 of deep_dw_kernel's X tile is all zero), weight 0.
@@ -168,7 +217,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                                                         const uint2 *__restrict__ segs,
                                                         const float *__restrict__ src,
                                                         const float *__restrict__ Bm, int N, int ntiles, int ntap,
-                                                        BlockMap bm, float *__restrict__ out,
+                                                        const uint32_t *__restrict__ sched, int sched_cap,
+                                                        float *__restrict__ out,
                                                         const uint32_t *__restrict__ tap_order,
                                                         const uint32_t *__restrict__ tap_off,
                                                         uint8_t *__restrict__ tile_flag)
@@ -197,8 +247,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     uint32_t *mcand = reinterpret_cast<uint32_t *>(mqr + kDeepBatch);
     int32_t *qorig = reinterpret_cast<int32_t *>(mcand + kDeepBatch);
 
-    int b, qt;
-    if (!block_to_cloud(bm, b, qt)) return;
+    // workgroup -> tile: XCD (blockIdx.x & 7, as in BlockMap) and position in that XCD's longest-first order
+    const uint32_t tile_sched = sched[(size_t)(blockIdx.x & 7) * sched_cap + (blockIdx.x >> 3)];
+    if (tile_sched == 0xFFFFFFFFu) return;
+    const int b = (int)(tile_sched / (uint32_t)ntiles), qt = (int)(tile_sched % (uint32_t)ntiles);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rb = wave & 1, cb0 = wave >> 1;             // this wave's row block and first column block
     const bool s_on = CBK >= 2 || wave < 2, o_on = CBN >= 2 || wave < 2;
