@@ -239,20 +239,18 @@ inline bool deep_shape(int elem, int cin, int cout);
 struct DeepScratch;
 size_t deep_scratch_bytes(const Dims &d, size_t pair_slots);
 
-size_t backward_scratch_bytes(const Dims &d, int elem)
+// ppp: pair slots per point of the buffer the call runs in (a cache may be configured with fewer than the default)
+size_t backward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
 {
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
-    if (deep_shape(elem, d.Cin, d.Cout)) {
-        size_t ppc = (size_t)d.N * kDefaultPairsPerPoint;
-        return deep_scratch_bytes(d, (size_t)d.B * ppc);
-    }
+    if (deep_shape(elem, d.Cin, d.Cout)) return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     const size_t slots = small_shape(elem, d.Cin, d.Cout) ? (size_t)grid_of(make_blockmap(d)) : 1;
     return nw * slots * (size_t)elem;
 }
 
-size_t forward_scratch_bytes(const Dims &d, int elem)
+size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
 {
-    if (deep_shape(elem, d.Cin, d.Cout)) return deep_scratch_bytes(d, (size_t)d.B * d.N * kDefaultPairsPerPoint);
+    if (deep_shape(elem, d.Cin, d.Cout)) return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     return 0;
 }
 
@@ -427,6 +425,7 @@ inline bool deep_shape(int elem, int cin, int cout)
     return false;
 }
 
+constexpr int kDwItems = 1024;        // target number of deep_dw_kernel work items (2 rounds at 2 per CU)
 struct DeepScratch {   // carved from the per-call scratch region
     float *wt;             // filter transposed [F][Cout][Cin]
     uint32_t *tap_order;   // per pair slot: tile tap-major record order
@@ -434,8 +433,10 @@ struct DeepScratch {   // carved from the per-call scratch region
     uint8_t *tile_flag;    // [tiles]
     uint32_t *sched;       // [8][sched_cap] launch order of the tiles per XCD (deep_sched_kernel)
     int sched_cap;
-    float *partials;       // [nchunks + 1][F*Cin*Cout]
-    int nchunks;
+    uint32_t *tap_total;   // [64] pairs per backward tap, then [1] number of work items  (deep_plan_kernel)
+    uint2 *tap_rng;        // [64] partial slots of each tap
+    uint4 *items;          // [kDwItems + 64] deep_dw_kernel work items
+    float *partials;       // [kDwItems + 64][Cin*Cout] item partials, then [F*Cin*Cout] the generic kernel's share
     size_t bytes;
 };
 
@@ -446,23 +447,16 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     char *p = static_cast<char *>(base);
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
-    // (tap, chunk) grid of deep_dw_kernel: ~3 rounds of workgroups at 2 per CU, so that the taps with many pairs
-    // (whose workgroups run longest, and are launched first) do not set the kernel's duration
-    s.nchunks = 1728 / d.ntap > 1 ? 1728 / d.ntap : 1;
-    const int tiles = d.B * d.ntiles;
-    if (s.nchunks > tiles) s.nchunks = tiles > 0 ? tiles : 1;
-    if (s.nchunks > 64) s.nchunks = 64;
-    if (const char *e = getenv("CONV3P_DW_CHUNKS")) {        // developer override (tools/deep_time.py)
-        const int v = atoi(e);
-        if (v >= 1 && v <= 64) s.nchunks = v;
-    }
     s.wt = reinterpret_cast<float *>(take(nw * 4));
     s.tap_order = reinterpret_cast<uint32_t *>(take(pair_slots * 4));
     s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
     s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
     s.sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
-    s.partials = reinterpret_cast<float *>(take(nw * 4 * (size_t)(s.nchunks + 1)));
+    s.tap_total = reinterpret_cast<uint32_t *>(take(65 * 4));
+    s.tap_rng = reinterpret_cast<uint2 *>(take(64 * 8));
+    s.items = reinterpret_cast<uint4 *>(take((size_t)(kDwItems + 64) * 16));
+    s.partials = reinterpret_cast<float *>(take((size_t)(kDwItems + 64) * d.Cin * d.Cout * 4 + nw * 4));
     s.bytes = off;
     return s;
 }
@@ -476,9 +470,13 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     const auto &S = c.L.slot[c.slot];
     const size_t lds = (size_t)18 * d.ntap * 4;
     Scope sc(K_DEEP_ORDER, c.s);
+    if (BWD) TRY(zero_async(ds.tap_total, 65 * 4, c.s));
     hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, S.pairs, S.segs,
-                       d.ntap, ds.tap_order, ds.tap_off, ds.tile_flag);
+                       d.ntap, ds.tap_order, ds.tap_off, ds.tile_flag, BWD ? ds.tap_total : nullptr);
     hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, S.segs, d.B, d.ntiles, ds.sched_cap, ds.sched);
+    if (BWD)
+        hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.tap_off, d.ntap, d.B * d.ntiles, kDwItems,
+                           ds.items, ds.tap_rng, ds.tap_total + 64);
     return hip_ok();
 }
 
@@ -534,31 +532,19 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
         Scope sc(K_DEEP_DW, c.s);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_dw_kernel<CI, CO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        // taps by distance from the stencil centre (ties: ascending tap index)
-        TapPerm perm;
-        {
-            int order[64], key[64];
-            for (int f = 0; f < d.ntap; ++f) {
-                const int tx = f % d.fx, ty = (f / d.fx) % d.fy, tz = f / (d.fx * d.fy);
-                key[f] = abs(2 * tx - (d.fx - 1)) + abs(2 * ty - (d.fy - 1)) + abs(2 * tz - (d.fz - 1));
-                order[f] = f;
-            }
-            std::stable_sort(order, order + d.ntap, [&](int a, int b) { return key[a] < key[b]; });
-            for (int f = 0; f < 64; ++f) perm.t[f] = (uint8_t)(f < d.ntap ? order[f] : 0);
-        }
-        hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(d.ntap, ds.nchunks), dim3(256), lds, c.s, c.L.pts, S.pairs,
-                           S.segs, ds.tap_order, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap, ds.nchunks,
-                           ds.tile_flag, perm, ds.partials);
+        hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(kDwItems + 64), dim3(256), lds, c.s, c.L.pts, S.pairs, S.segs,
+                           ds.tap_order, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap, ds.tile_flag, ds.items,
+                           ds.tap_total + 64, ds.partials);
     }
     TRY(hip_ok());
-    // flagged tiles: generic kernel adds into the zeroed rows / into the extra partial slot
-    float *extra = ds.partials + nw * (size_t)ds.nchunks;
+    // flagged tiles: generic kernel adds into the zeroed rows / into its own grad_filter-shaped buffer
+    float *extra = ds.partials + (size_t)(kDwItems + 64) * CI * CO;
     TRY(zero_async(extra, nw * 4, c.s));
     TRY((launch_backward<float, 0, 0>(c, grad_out, input, filter, grad_input, extra, ds.tile_flag)));
     {
         Scope sc(K_REDUCE, c.s);
-        hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3((unsigned)((nw + 63) / 64)), dim3(1024), 0, c.s,
-                           ds.partials, ds.nchunks + 1, nw, grad_filter);
+        hipLaunchKernelGGL(deep_reduce_kernel, dim3((unsigned)((CI * CO + 255) / 256), (unsigned)d.ntap), dim3(256), 0, c.s,
+                           ds.partials, ds.tap_rng, extra, CI * CO, grad_filter);
     }
     return hip_ok();
 }
@@ -669,7 +655,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     if (Cin == 0) return zero_async(output, out_elems * sizeof(T), s);   // empty contraction; selu(0) == 0
     Call<T> c;
     c.act = act;
-    TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T)), wh, s));
+    TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     if constexpr (sizeof(T) == 4) {
@@ -790,7 +776,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     Call<T> c;
     c.act = act;
     c.addend = addend;
-    TRY(begin_call<T>(c, d, stride, voxel, backward_scratch_bytes(d, (int)sizeof(T)), wh, s));
+    TRY(begin_call<T>(c, d, stride, voxel, backward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     int rc = CONV3P_ERR_UNSUPPORTED;

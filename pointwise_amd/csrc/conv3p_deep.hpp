@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__rest
                                                          const uint2 *__restrict__ segs, int ntap,
                                                          uint32_t *__restrict__ tap_order,
                                                          uint32_t *__restrict__ tap_off,
-                                                         uint8_t *__restrict__ tile_flag)
+                                                         uint8_t *__restrict__ tile_flag,
+                                                         uint32_t *__restrict__ tap_total)   // [ntap] += (may be null)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *tot = reinterpret_cast<uint32_t *>(smem);            // [ntap]     records per tap (whole tile)
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__rest
         if (k != 0xFFFFFFFFu) atomicAdd(&tot[k], 1u);
     }
     __syncthreads();
+    if (tap_total != nullptr && tid < (uint32_t)ntap && tot[tid] != 0) atomicAdd(&tap_total[tid], tot[tid]);
     if (tid == 0) {
         uint32_t run = 0;
         for (int f = 0; f < ntap; ++f) {
@@ -431,13 +433,171 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     }
 }
 
-// Launch order of the taps in deep_dw_kernel.  A tap's workgroups cost in proportion to its number of pairs, and
-// on surface-like clouds the central tap holds ~3x the average, the corner taps far less: the (tap, chunk) grid
-// is issued with the taps nearest to the stencil centre first, so that the long workgroups start first and the
-// short ones fill in behind them.
-struct TapPerm {
-    uint8_t t[64];
-};
+// ---------------------------------------------------------------------------------------------
+// deep_plan_kernel: work items of deep_dw_kernel.  The cost of (tile, tap) is proportional to its number of
+// pairs: on surface-like clouds the central tap holds ~3x the average tap's and boundary tiles a fraction of an
+// interior tile's, so neither equal tile ranges nor equal tap shares balance the workgroups.  Tap f gets
+// n_f ~ (its share of all pairs) x `target` items (exactly `target` in total: a whole number of rounds of the
+// resident workgroups), and its tiles are cut into n_f ranges of equal WORK (32-record blocks + a fixed cost per
+// populated tile, from a prefix sum over tap_off).  Items are issued in order of their first tile, so that the
+// items running together read the same rows (L2); item j of tap f writes partial slot ibeg_f + j.
+//   items[i] = {tap, first tile, end tile, slot};  tap_rng[f] = {ibeg_f, n_f};  *nitems = number of items
+// One workgroup of 1024 threads.  More than kPlanTiles tiles: equal tile ranges.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPlanMax = 2048;
+constexpr int kPlanTiles = 8192;
+__global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restrict__ tap_total,
+                                                         const uint32_t *__restrict__ tap_off, int ntap, int tiles,
+                                                         int target, uint4 *__restrict__ items,
+                                                         uint2 *__restrict__ tap_rng, uint32_t *__restrict__ nitems)
+{
+    __shared__ unsigned long long keys[kPlanMax];
+    __shared__ uint32_t t1s[kPlanMax];
+    __shared__ uint32_t prefix[kPlanTiles];
+    __shared__ uint32_t nf[64], ibeg[65], wtot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) {
+        // n_f = floor share, at least 1, at most one item per tile; the items left over go to the taps with the
+        // largest remainders, so that the total is EXACTLY `target` whenever that is possible
+        unsigned long long sum = 0;
+        for (int f = 0; f < ntap; ++f) sum += tap_total[f];
+        uint32_t rem[64];
+        uint32_t used = 0;
+        for (int f = 0; f < ntap; ++f) {
+            const unsigned long long share = sum ? (unsigned long long)tap_total[f] * (unsigned)target : 0ull;
+            uint32_t n = sum ? (uint32_t)(share / sum) : 1u;
+            rem[f] = sum ? (uint32_t)(share % sum * 1024ull / sum) : 0u;
+            if (n < 1u) { n = 1u; rem[f] = 0; }
+            if (n > (uint32_t)tiles) { n = (uint32_t)tiles; rem[f] = 0; }
+            if (n < 1u) n = 1u;
+            nf[f] = n;
+            used += n;
+        }
+        while (used < (uint32_t)target) {
+            int best = -1;
+            for (int f = 0; f < ntap; ++f)
+                if (nf[f] < (uint32_t)tiles && rem[f] > 0 && (best < 0 || rem[f] > rem[best])) best = f;
+            if (best < 0) break;
+            nf[best] += 1;
+            rem[best] = 0;
+            used += 1;
+        }
+        uint32_t run = 0;
+        for (int f = 0; f < ntap; ++f) {
+            ibeg[f] = run;
+            tap_rng[f] = make_uint2(run, nf[f]);
+            run += nf[f];
+        }
+        ibeg[ntap] = run;
+        *nitems = run;
+    }
+    __syncthreads();
+    const uint32_t total = ibeg[ntap];                       // <= target + ntap <= kPlanMax (host checks)
+    const uint32_t T = (uint32_t)tiles;
+    for (int f = 0; f < ntap; ++f) {
+        const uint32_t n = nf[f], i0 = ibeg[f];
+        if (T > (uint32_t)kPlanTiles) {                      // too many tiles for the LDS prefix: equal tile ranges
+            for (uint32_t j = tid; j < n; j += 1024) {
+                const uint32_t t0 = (uint32_t)((unsigned long long)j * T / n);
+                keys[i0 + j] = ((unsigned long long)t0 << 32) | ((unsigned long long)f << 16) | j;
+                t1s[i0 + j] = (uint32_t)((unsigned long long)(j + 1) * T / n);
+            }
+            continue;
+        }
+        // work of every tile for this tap -> inclusive prefix (thread = contiguous run of `per` tiles)
+        const uint32_t per = (T + 1023u) / 1024u;
+        uint32_t w[kPlanTiles / 1024], mine = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) {
+            const uint32_t t = tid * per + u;
+            w[u] = 0;
+            if (u < per && t < T) {
+                const uint32_t c = tap_off[(size_t)t * (ntap + 1) + f + 1] - tap_off[(size_t)t * (ntap + 1) + f];
+                w[u] = c ? (c + 31u) / 32u + 2u : 0u;         // blocks of 32 records + the tile's fixed cost
+            }
+            mine += w[u];
+        }
+        int wsum;
+        uint32_t excl = (uint32_t)wave_excl_scan((int)mine, wsum);
+        if (lane == 0) wtot[wave] = (uint32_t)wsum;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < wave; ++k) base += wtot[k];
+        excl += base;
+#pragma unroll
+        for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) {
+            const uint32_t t = tid * per + u;
+            excl += w[u];
+            if (u < per && t < T) prefix[t] = excl;
+        }
+        __syncthreads();
+        const unsigned long long wall = prefix[T - 1];
+        // boundary b_j = first tile whose inclusive prefix exceeds j * wall / n  (b_0 = 0 by construction: item 0
+        // starts at the first tile; empty leading tiles cost nothing)
+        for (uint32_t j = tid; j < n; j += 1024) {
+            auto bound = [&](uint32_t jj) -> uint32_t {
+                if (jj == 0) return 0u;
+                if (jj >= n) return T;
+                const uint32_t goal = (uint32_t)(wall * jj / n);
+                uint32_t lo = 0, hi = T;                      // first t with prefix[t] > goal
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (prefix[mid] > goal) hi = mid; else lo = mid + 1;
+                }
+                return lo;
+            };
+            const uint32_t t0 = bound(j);
+            keys[i0 + j] = ((unsigned long long)t0 << 32) | ((unsigned long long)f << 16) | j;
+            t1s[i0 + j] = bound(j + 1);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // issue order: by first tile (then tap); t1 travels in a second array addressed by slot
+    uint32_t npad = 1;
+    while (npad < total) npad <<= 1;
+    for (uint32_t i = total + tid; i < npad; i += 1024) keys[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= npad; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < npad; t += 1024) {
+                const uint32_t p = t ^ j;
+                if (p > t) {
+                    const unsigned long long a = keys[t], b = keys[p];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { keys[t] = b; keys[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < total; i += 1024) {
+        const uint32_t f = (uint32_t)(keys[i] >> 16) & 0xFFFFu, j = (uint32_t)keys[i] & 0xFFFFu;
+        const uint32_t slot = ibeg[f] + j;
+        items[i] = make_uint4(f, (uint32_t)(keys[i] >> 32), t1s[slot], slot);
+    }
+}
+
+// grad_filter[f] = sum of tap f's item partials (ascending j: fixed order) + the generic kernel's contribution
+__global__ __launch_bounds__(256) void deep_reduce_kernel(const float *__restrict__ partials,
+                                                          const uint2 *__restrict__ tap_rng,
+                                                          const float *__restrict__ extra, int per_tap,
+                                                          float *__restrict__ grad_filter)
+{
+    const int f = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per_tap) return;
+    const uint2 rg = tap_rng[f];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    uint32_t j = 0;
+    for (; j + 4 <= rg.y; j += 4) {
+        s0 += partials[(size_t)(rg.x + j) * per_tap + e];
+        s1 += partials[(size_t)(rg.x + j + 1) * per_tap + e];
+        s2 += partials[(size_t)(rg.x + j + 2) * per_tap + e];
+        s3 += partials[(size_t)(rg.x + j + 3) * per_tap + e];
+    }
+    for (; j < rg.y; ++j) s0 += partials[(size_t)(rg.x + j) * per_tap + e];
+    grad_filter[(size_t)f * per_tap + e] = ((s0 + s1) + (s2 + s3)) + extra[(size_t)f * per_tap + e];
+}
 
 // ---------------------------------------------------------------------------------------------
 // deep_dw_kernel: grad_filter partials.  Workgroup = (backward tap f, chunk of query tiles):
@@ -450,15 +610,11 @@ struct TapPerm {
 // LDS: X tile [64][CIN+1] | rows [32][COUT+32] | meta [256] x 3 | qorig [64]
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void deep_dw_kernel(const PointRec<float> *__restrict__ pts,
-                                                      const PairEntry *__restrict__ pairs,
-                                                      const uint2 *__restrict__ segs,
-                                                      const uint32_t *__restrict__ tap_order,
-                                                      const uint32_t *__restrict__ tap_off,
-                                                      const float *__restrict__ grad_out,
-                                                      const float *__restrict__ input, int B, int N, int ntiles,
-                                                      int ntap, int nchunks, const uint8_t *__restrict__ tile_flag,
-                                                      TapPerm tapperm, float *__restrict__ partials)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void deep_dw_kernel(
+    const PointRec<float> *__restrict__ pts, const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs,
+    const uint32_t *__restrict__ tap_order, const uint32_t *__restrict__ tap_off, const float *__restrict__ grad_out,
+    const float *__restrict__ input, int B, int N, int ntiles, int ntap, const uint8_t *__restrict__ tile_flag,
+    const uint4 *__restrict__ items, const uint32_t *__restrict__ nitems, float *__restrict__ partials)
 {
     constexpr int LDX = CIN + 1;
     constexpr int LDR = COUT + 32;
@@ -479,7 +635,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     int32_t *qorig = reinterpret_cast<int32_t *>(mcand + kDeepBatch);
     for (int e = threadIdx.x; e < LDX; e += 256) X[64 * LDX + e] = 0.0f;
 
-    const int f = tapperm.t[blockIdx.x], chunk = blockIdx.y;   // taps fastest: the 27 workgroups of a chunk share its rows in L2
+    if (blockIdx.x >= *nitems) return;
+    const uint4 item = items[blockIdx.x];                  // {tap, first tile, end tile, partial slot}
+    const int f = (int)item.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave / WN, wn = wave % WN;
     const bool w_on = MB % WM == 0 || wm < MB;             // (32-channel inputs: only the first row of waves)
@@ -491,9 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const size_t total_tiles = (size_t)B * ntiles;
-    const size_t per = (total_tiles + nchunks - 1) / nchunks;
-    const size_t t0 = per * chunk, t1 = (t0 + per < total_tiles) ? t0 + per : total_tiles;
+    const size_t t0 = item.y, t1 = item.z;
 #if CONV3P_ABLATE & 16777216
     long long tk[6] = {0, 0, 0, 0, 0, 0};
     long long nblk_dbg = 0, ntile_dbg = 0;
@@ -609,13 +765,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #endif
     }
 #if CONV3P_ABLATE & 16777216
-    if (threadIdx.x == 0 && f == 13 && blockIdx.y == 1)
+    if (threadIdx.x == 0 && f == 13 && (item.w & 15) == 1)
         printf("dw dbg (100 MHz ticks): tiles %lld blocks %lld | loop-head %lld  meta %lld  X+rows0 %lld  store+sync %lld  loads+mfma %lld  sync2 %lld\n",
                ntile_dbg, nblk_dbg, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
 #endif
 
-    // partial slot of this chunk: layout of grad_filter, [(f*CIN + k)*COUT + c]
-    float *slot = partials + (size_t)chunk * ntap * CIN * COUT + (size_t)f * CIN * COUT;
+    // partial slot of this item: [k][c]
+    float *slot = partials + (size_t)item.w * CIN * COUT;
     if (w_on) {
 #pragma unroll
         for (int i = 0; i < PM; ++i)
