@@ -639,8 +639,10 @@ __global__ __launch_bounds__(256) void finalise_multi_kernel(const PointRec<T> *
 // A segment marked kSegOverflow makes the workgroup search its query tile itself.
 // ---------------------------------------------------------------------------------
 template <typename T, int CIN, int COUT>
-// 4 waves per SIMD = 4 workgroups per CU: the 128 workgroups an XCD gets for cfg2 are resident in one round
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void forward_kernel(
+// Cin <= 12: 4 waves per SIMD = 4 workgroups per CU, so that the 128 workgroups an XCD gets for cfg2 are resident
+// in one round (the unconstrained allocation is 132 VGPRs).  Wider inputs keep their row in registers and would
+// spill under that cap (36 -> 13: 50 spilled VGPRs, 4.6x slower).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN > 0 && CIN <= 12 ? 4 : 1))) void forward_kernel(
 
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
