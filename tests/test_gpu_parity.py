@@ -558,3 +558,30 @@ def test_deep_channel_path_non_finite_values_reach_only_their_neighbours(dev):
         assert np.array_equal(~np.isfinite(got), bad_ref)
         ok = ~bad_ref
         assert np.max(np.abs(got[ok] - ref[ok])) <= tol * max(1.0, np.max(np.abs(ref[ok])))
+
+
+def _fuzz_cases():
+    rng = np.random.RandomState(20260927)
+    shapes = [(3, 9), (9, 9), (36, 13), (5, 7), (1, 1), (32, 64), (64, 64), (9, 3), (12, 9), (2, 17)]
+    kinds = ["modelnet", "room", "cube", "lattice"]
+    out = []
+    for i in range(28):
+        ci, co = shapes[rng.randint(len(shapes))]
+        B = int(rng.randint(1, 4))
+        N = int(rng.choice([1, 5, 63, 64, 65, 130, 257, 500]))
+        f = tuple(int(v) for v in rng.choice([1, 2, 3], size=3))
+        st = tuple(int(v) for v in rng.choice([1, 2, 3, 4], size=3))
+        dt = np.float64 if (ci, co) in ((5, 7), (1, 1)) and rng.rand() < 0.5 else np.float32
+        out.append((kinds[rng.randint(len(kinds))], B, N, ci, co, f, st, dt, 3000 + i))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "%s-B%dN%d-%dto%d-f%s-s%s-%s" % (
+    c[0], c[1], c[2], c[3], c[4], "".join(map(str, c[5])), "".join(map(str, c[6])), c[7].__name__))
+def test_random_shapes_against_oracle(dev, case):
+    """Seeded random mix of cloud kinds, ragged sizes, filter extents, anisotropic strides and channel shapes
+    (register path, generic path, deep path, fp64): every kernel family against the oracle."""
+    kind, B, N, ci, co, f, st, dt, seed = case
+    P, X, W, dY = make_case(kind, B, N, ci, co, f, seed=seed, dtype=dt)
+    ref = (oracle.neighbor_count(P, f, st, VOX), oracle.forward(P, X, W, st, VOX)) + oracle.backward(dY, P, X, W, st, VOX)
+    check_against(ref, run_hip(dev, P, X, W, dY, st), dt)
