@@ -364,7 +364,8 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    const size_t lds = lds_common(st) + (CI > 0 ? a16(nw * sizeof(T)) : 0) + a16((size_t)st.ntap * kCntStride * 4) +
+    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * ((CI * CO) | 1) * sizeof(T)) : 0) +
+                       a16((size_t)st.ntap * kCntStride * 4) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
                        (CI > 0 ? a16((size_t)kWavesPerBlock * CO * 64 * sizeof(T)) : 0);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;

@@ -658,7 +658,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN > 0 && 
     size_t off = align16((size_t)3 * st.maxfull * 2);
     T *w_lds = reinterpret_cast<T *>(smem + off);
     const size_t nw = (size_t)st.ntap * cin * cout;
-    if (kSmall) off += align16(nw * sizeof(T));
+    // LDS stride of one tap's [Cin][Cout] block: odd, so that lanes working on different taps spread over all the
+    // banks (36 x 13 = 468 = 20 mod 32 would put every tap on one of 8 banks: the 36 -> 13 layer ran 2x slower)
+    constexpr int WSTR = kSmall ? ((CIN * COUT) | 1) : 1;
+    if (kSmall) off += align16((size_t)st.ntap * WSTR * sizeof(T));
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
     off += align16((size_t)st.ntap * kCntStride * 4);
     int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
@@ -678,7 +681,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN > 0 && 
             for (int u = 0; u < 8; ++u) v[u] = e0 + u * 256 < (uint32_t)nw ? filter[e0 + u * 256] : (T)0;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (e0 + u * 256 < (uint32_t)nw) w_lds[e0 + u * 256] = v[u];
+                if (e0 + u * 256 < (uint32_t)nw) {
+                    const uint32_t e = e0 + u * 256, f = e / (CIN * COUT);
+                    w_lds[f * WSTR + (e - f * (CIN * COUT))] = v[u];
+                }
         }
     }
     int b, qt;
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN > 0 && 
             RowLoader<T, CIN>::load(xr, xs);
 #pragma unroll
             for (int k = 0; k < CIN; ++k) xs[k] *= rcp;                  // x / count, .cpp:492
-            const T *wf = w_lds + (size_t)f * CIN * COUT;
+            const T *wf = w_lds + (size_t)f * WSTR;
 #pragma unroll
             for (int k = 0; k < CIN; ++k)
 #pragma unroll
