@@ -92,7 +92,7 @@ int conv3p_backward_f64(const double *grad_out, const double *points, const doub
 /* ---------------------------------------------------------------------------------------------
  * Neighbour cache (optional; not in the reference).
  *
- * Everything geometric the ops compute -- Morton-sorted point records, per-tap populations and
+ * Everything geometric the ops compute -- curve-sorted point records, per-tap populations and
  * the per-centre neighbour lists with their taps and normalisers -- depends only on `points` and
  * on the stencil (filter extents, stride, voxel_size), not on features, weights or gradients.
  * In the reference's models every layer of a step sees the same `points`, and Conv3pGrad repeats

@@ -9,7 +9,9 @@
 //   prep_sort_kernel   hash the clouds; re-sort + re-box only clouds whose content changed
 //   search_kernel      per-tap populations + centre-major pair lists   (skipped per cloud when
 //   finalise_kernel    normalisers of every pair                        the slot is current)
-//   forward_kernel / backward_kernel + reduce_partials_kernel          the accumulation
+//   forward_kernel / backward_kernel + reduce_partials_kernel          the accumulation (register path), or
+//   deep_order / deep_sched / deep_plan + deep_gemm / deep_dw / deep_reduce   (matrix-core path, conv3p_deep.hpp), or
+//   the generic forms of forward_kernel / backward_kernel (any channel counts, fp64)
 // The stateless entry points run the same kernels on the caller's scratch with force = 1.
 #include "../../include/conv3p.h"
 #include "conv3p_kernels.hpp"

@@ -5,7 +5,7 @@
 // memory and does one global float atomic per (pair, k, c)):
 //
 //   * a cloud is cut into TILES of 64 points = one wavefront; a prep kernel orders the
-//     points along a Morton curve, stores each as a 16-byte record {x, y, z, original index}
+//     points along a Hilbert curve, stores each as a 16-byte record {x, y, z, original index}
 //     and stores every tile's bounding box;
 //   * one WORKGROUP owns one QUERY tile (lane = centre point, all waves hold the same 64
 //     centres); its waves split the CANDIDATE tiles that survive a bounding-box cull
@@ -240,7 +240,7 @@ __device__ __forceinline__ int exact_tap(const PointRec<T> &v, const Query<T> &q
 // multiplied by inv = 1/(step*voxel), to the wave's SoA slot (soa[0..63] = x, [64..127] = y,
 // [128..191] = z), so that the per-pair arithmetic starts with a v_add instead of a v_fma.
 // Returns the quad mask: bits 4k..4k+3 are set iff the bounding box of candidates 4k..4k+3 (consecutive in
-// Morton order, so compact) meets the wave's acceptance range; scan_tile skips the other quads.
+// Hilbert order, so compact) meets the wave's acceptance range; scan_tile skips the other quads.
 __device__ __forceinline__ float quad_swap1(float v)   // lanes {0,1,2,3} -> {1,0,3,2}
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
