@@ -585,3 +585,28 @@ def test_random_shapes_against_oracle(dev, case):
     P, X, W, dY = make_case(kind, B, N, ci, co, f, seed=seed, dtype=dt)
     ref = (oracle.neighbor_count(P, f, st, VOX), oracle.forward(P, X, W, st, VOX)) + oracle.backward(dY, P, X, W, st, VOX)
     check_against(ref, run_hip(dev, P, X, W, dY, st), dt)
+
+
+def test_bench_prints_one_contract_json_line(dev):
+    """bench.py's stdout is ONE JSON line with the driver's fields plus the roofline / cpu_baseline objects."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "Mpoints/s" and d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["unit"] in ("GB/s", "TFLOP/s")
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
