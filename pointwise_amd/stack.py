@@ -77,6 +77,16 @@ class Conv3pStack:
             self._caches[idx] = c
         return c
 
+    def prepare(self, B, N):
+        """Set-up outside any timed region: allocate both neighbour caches for (B, N) clouds."""
+        if self.use_cache:
+            for idx in (0, 1):
+                cmax = max(max(ci, co) for ci, co, _ in self.layers)
+                c = self._caches[idx]
+                if c is None or not c.fits(B, N, self.dtype, self.device, 27, cmax, cmax):
+                    self._caches[idx] = op.NeighborCache(B, N, self.dtype, self.device, slots=len(self.layers),
+                                                         max_taps=27, max_cin=cmax, max_cout=cmax)
+
     def _cache_for(self, points):
         if not self.use_cache:
             return None
