@@ -230,7 +230,7 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
 
 inline bool small_shape(int elem, int cin, int cout)
 {
-    if (elem != 4) return false;   // fp64 always takes the generic path
+    (void)elem;   // fp32 and fp64 (the kernels are templates on T; shapes whose LDS does not fit fall back at launch)
 #define X(ci, co) if (cin == ci && cout == co) return true;
     CONV3P_SMALL_SHAPES(X)
 #undef X
@@ -661,14 +661,14 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
-    if constexpr (sizeof(T) == 4) {
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \
         int rc = launch_forward<T, ci, co>(c, input, filter, output);                                \
         if (rc != CONV3P_ERR_UNSUPPORTED) return rc;                                                 \
     }
-        CONV3P_SMALL_SHAPES(X)
+    CONV3P_SMALL_SHAPES(X)
 #undef X
+    if constexpr (sizeof(T) == 4) {
         if (c.L.ngroups == 1 && c.deep_scratch_ok) {
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \
@@ -784,11 +784,11 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     int rc = CONV3P_ERR_UNSUPPORTED;
     int nslots = (int)grid_of(make_blockmap(d));
-    if constexpr (sizeof(T) == 4) {
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input);
-        CONV3P_SMALL_SHAPES(X)
+    CONV3P_SMALL_SHAPES(X)
 #undef X
+    if constexpr (sizeof(T) == 4) {
         if (rc == CONV3P_ERR_UNSUPPORTED && c.L.ngroups == 1 && c.deep_scratch_ok) {
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \

@@ -142,6 +142,26 @@ __device__ __forceinline__ uint32_t lane_xor32(uint32_t x)
     return (threadIdx.x & 32) ? r[0] : r[1];
 }
 
+// typed forms (fp64 values travel as two 32-bit halves)
+__device__ __forceinline__ float lane_xor16(float v) { return __builtin_bit_cast(float, lane_xor16(__builtin_bit_cast(uint32_t, v))); }
+__device__ __forceinline__ float lane_xor32(float v) { return __builtin_bit_cast(float, lane_xor32(__builtin_bit_cast(uint32_t, v))); }
+__device__ __forceinline__ double lane_xor16(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned long long r = (unsigned long long)lane_xor16((uint32_t)b) | ((unsigned long long)lane_xor16((uint32_t)(b >> 32)) << 32);
+    return __builtin_bit_cast(double, r);
+}
+__device__ __forceinline__ double lane_xor32(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned long long r = (unsigned long long)lane_xor32((uint32_t)b) | ((unsigned long long)lane_xor32((uint32_t)(b >> 32)) << 32);
+    return __builtin_bit_cast(double, r);
+}
+// 1/count in T from the pair record's fp32 1/count: exact for fp32; for fp64 the count (an integer < 2^23) is
+// recovered exactly and the reciprocal taken in double (the reference divides by the count in T, .cpp:492, :692)
+__device__ __forceinline__ float rcp_in(float r, float) { return r; }
+__device__ __forceinline__ double rcp_in(float r, double) { return 1.0 / (double)__builtin_rintf(1.0f / r); }
+
 template <typename T> struct Limits;
 template <> struct Limits<float> {
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }

@@ -642,7 +642,7 @@ template <typename T, int CIN, int COUT>
 // Cin <= 12: 4 waves per SIMD = 4 workgroups per CU, so that the 128 workgroups an XCD gets for cfg2 are resident
 // in one round (the unconstrained allocation is 132 VGPRs).  Wider inputs keep their row in registers and would
 // spill under that cap (36 -> 13: 50 spilled VGPRs, 4.6x slower).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN > 0 && CIN <= 12 ? 4 : 1))) void forward_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && CIN > 0 && CIN <= 12 ? 4 : 1))) void forward_kernel(
 
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN > 0 && 
                     const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
                     if (i < sg.y) {
                         const uint32_t f = code_fwd(cur.code);
-                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)cq, (T)cur.rcp_fwd);
+                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)cq, rcp_in(cur.rcp_fwd, (T)0));
                     }
                     cur = nxt;
                 }
@@ -965,8 +965,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
                         bool pending = live_rec(cur, i);
                         const uint32_t fb = code_bwd(cur.code);
                         if (pending) {
+                            const T rcpb = rcp_in(cur.rcp_bwd, (T)0);
 #pragma unroll
-                            for (int c = 0; c < COUT; ++c) val[c] *= (T)cur.rcp_bwd;
+                            for (int c = 0; c < COUT; ++c) val[c] *= rcpb;
                         }
                         if (CONV3P_ABLATE & 256) {
                             if (pending) {
@@ -1001,10 +1002,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
                             if (__any(same)) {
 #pragma unroll
                                 for (int c = 0; c < COUT; ++c) {
-                                    const uint32_t bits = __builtin_bit_cast(uint32_t, (float)val[c]);
-                                    const uint32_t pb = step == 0 ? lane_xor16(bits)
-                                                      : step == 1 ? lane_xor32(bits) : lane_xor32(lane_xor16(bits));
-                                    if (same && lower) val[c] += (T)__builtin_bit_cast(float, pb);
+                                    const T pv = step == 0 ? lane_xor16(val[c])
+                                               : step == 1 ? lane_xor32(val[c]) : lane_xor32(lane_xor16(val[c]));
+                                    if (same && lower) val[c] += pv;
                                 }
                                 if (same && !lower) pending = false;
                             }

@@ -610,3 +610,20 @@ def test_bench_prints_one_contract_json_line(dev):
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["unit"] in ("GB/s", "TFLOP/s")
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+
+
+@pytest.mark.parametrize("ci,co,kind,N", [(9, 9, "modelnet", 600), (3, 9, "room", 300), (36, 13, "room", 200), (9, 3, "lattice", 256)])
+def test_fp64_register_path_matches_oracle(dev, ci, co, kind, N):
+    """The reference registers T in {float, double} (register_op.cpp:44-75): the models' shapes in fp64 take the
+    same register-path kernels (templates on T; 36->13 falls back to the generic backward: its G does not fit LDS),
+    within the fp64 tolerance, and stay bitwise reproducible."""
+    B = 2
+    P, X, W, dY = make_case(kind, B, N, ci, co, seed=1100, dtype=np.float64)
+    s = (2, 1, 2)
+    ref = (oracle.neighbor_count(P, (3, 3, 3), s, VOX), oracle.forward(P, X, W, s, VOX)) + oracle.backward(dY, P, X, W, s, VOX)
+    got = run_hip(dev, P, X, W, dY, s)
+    check_against(ref, got, np.float64)
+    if (ci, co) != (36, 13):
+        again = run_hip(dev, P, X, W, dY, s)
+        for a, b in zip(got, again):
+            assert np.array_equal(a, b)
