@@ -241,13 +241,29 @@ inline bool deep_shape(int elem, int cin, int cout);
 struct DeepScratch;
 size_t deep_scratch_bytes(const Dims &d, size_t pair_slots);
 
+// Generic backward: every pair adds Cin*Cout products to grad_filter with global atomics.  One shared copy
+// serialises them all on the same few addresses (cfg2-sized 5->7: 67 ms); the workgroups therefore spread over
+// `slots` partial copies (workgroup % slots), at most one per workgroup and at most 64 MiB in total, summed by
+// reduce_partials_kernel.
+inline int generic_slots(const Dims &d, int elem)
+{
+    const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
+    const size_t grid = (size_t)grid_of(make_blockmap(d));
+    size_t s = nw ? ((size_t)64 << 20) / (nw * (size_t)elem) : 1;
+    if (s > grid) s = grid;
+    return s < 1 ? 1 : (int)s;
+}
+
 // ppp: pair slots per point of the buffer the call runs in (a cache may be configured with fewer than the default)
 size_t backward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
 {
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
-    if (deep_shape(elem, d.Cin, d.Cout)) return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
-    const size_t slots = small_shape(elem, d.Cin, d.Cout) ? (size_t)grid_of(make_blockmap(d)) : 1;
-    return nw * slots * (size_t)elem;
+    size_t deep = 0;
+    if (deep_shape(elem, d.Cin, d.Cout)) deep = deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+    // register path: one partial per workgroup; generic path (also the fallback of the other two): generic_slots
+    const size_t slots = small_shape(elem, d.Cin, d.Cout) ? (size_t)grid_of(make_blockmap(d)) : (size_t)generic_slots(d, elem);
+    const size_t plain = nw * slots * (size_t)elem;
+    return deep > plain ? deep : plain;
 }
 
 size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
@@ -383,7 +399,7 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
 
 template <typename T, int CI, int CO>
 int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T *filter, T *grad_input,
-                    T *partials = nullptr, const uint8_t *only_flagged = nullptr)
+                    T *partials = nullptr, const uint8_t *only_flagged = nullptr, int gen_slots = 1)
 {
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
@@ -402,7 +418,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
-                       (CI > 0 && c.act) ? 1 : 0, c.addend);
+                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots);
     return hip_ok();
 }
 
@@ -801,11 +817,14 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
 #undef X
         }
     }
+    bool generic = false;
     if (rc == CONV3P_ERR_UNSUPPORTED) {
-        nslots = 1;
+        generic = true;
+        nslots = generic_slots(d, (int)sizeof(T));
+        if (small_shape((int)sizeof(T), Cin, Cout) && nslots > (int)grid_of(make_blockmap(d))) nslots = (int)grid_of(make_blockmap(d));
         TRY(zero_async(grad_input, dx_elems * sizeof(T), s));
-        TRY(zero_async(c.L.partials, nw * sizeof(T), s));
-        rc = launch_backward<T, 0, 0>(c, grad_out, input, filter, grad_input);
+        TRY(zero_async(c.L.partials, nw * (size_t)nslots * sizeof(T), s));
+        rc = launch_backward<T, 0, 0>(c, grad_out, input, filter, grad_input, nullptr, nullptr, nslots);
     }
     TRY(rc);
     {
@@ -814,7 +833,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
                            c.L.partials, nslots, nw, grad_filter);
     }
     TRY(hip_ok());
-    if (act && nslots == 1)   // generic path has no fused epilogue
+    if (act && generic)   // generic path has no fused epilogue
         return selu_grad_impl<T>(input, grad_input, addend, grad_input, dx_elems, stream);
     return CONV3P_OK;
 }
@@ -865,12 +884,26 @@ size_t layout_bytes(int elem, int B, int N, int ntap, int nslots, int ppp, size_
 
 size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, int max_Cout, int ppp)
 {
+    // the largest need of any (Cin <= max_Cin, Cout <= max_Cout, taps <= max_taps) call: register-path shapes take
+    // one partial per workgroup, every other shape the generic path's capped set of partials, deep shapes their own
     Dims d{B, N, max_Cin, max_Cout, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};
-    size_t b = (size_t)max_taps * max_Cin * max_Cout * (size_t)grid_of(make_blockmap(d)) * (size_t)elem;
-    if (deep_shape(elem, max_Cin, max_Cout)) {
-        const size_t deep = deep_scratch_bytes(d, (size_t)B * N * (size_t)ppp);
-        if (deep > b) b = deep;
+    const size_t grid = (size_t)grid_of(make_blockmap(d));
+    size_t b = (size_t)max_taps * max_Cin * max_Cout * (size_t)generic_slots(d, elem) * (size_t)elem;
+#define X(ci, co)                                                                                    \
+    if (ci <= max_Cin && co <= max_Cout) {                                                           \
+        const size_t need = (size_t)max_taps * ci * co * grid * (size_t)elem;                        \
+        if (need > b) b = need;                                                                      \
     }
+    CONV3P_SMALL_SHAPES(X)
+#undef X
+#define X(ci, co)                                                                                    \
+    if (elem == 4 && ci <= max_Cin && co <= max_Cout) {                                              \
+        Dims dd{B, N, ci, co, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};                    \
+        const size_t need = deep_scratch_bytes(dd, (size_t)B * N * (size_t)ppp);                     \
+        if (need > b) b = need;                                                                      \
+    }
+    CONV3P_DEEP_SHAPES(X)
+#undef X
     return b;
 }
 

@@ -830,8 +830,10 @@ __global__ __launch_bounds__(256) void backward_kernel(
     const T *__restrict__ grad_out, const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st,
     int N, int ntiles, int ngroups, int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ grad_input,
     T *__restrict__ partials, const uint8_t *__restrict__ only_flagged,
-    int act, const T *__restrict__ addend)   // act != 0 (small path only): `input` is a SELU output; store
+    int act, const T *__restrict__ addend,   // act != 0 (small path only): `input` is a SELU output; store
                                              // (dX + addend) * selu'(input), the gradient w.r.t. that SELU's argument
+    int gen_slots)                           // generic path: number of grad_filter partial slots the workgroups
+                                             // spread their atomics over (slot = workgroup % gen_slots)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
             } else {
                 const int jo = qorig[ql];
                 const T *wf = filter + (size_t)fb * cin * cout;
-                T *dwf = partials + (size_t)fb * cin * cout;
+                T *dwf = partials + (size_t)(blockIdx.x % (unsigned)gen_slots) * nw + (size_t)fb * cin * cout;
                 const T *xr = in_cloud + (size_t)jo * cin;
                 T *dxr = dx_cloud + (size_t)jo * cin;
                 for (int k = 0; k < cin; ++k) {
