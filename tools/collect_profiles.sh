@@ -30,5 +30,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_deep_trace -o t -- python $ROOT/
 python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_trace/t_results.db deep > $OUT/${TAG}_deep_kernel_stats.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_deep_pmc -o p -- python $ROOT/tools/deep_time.py > $OUT/${TAG}_deep_pmc.log 2>&1
 python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_pmc/p_results.db deep > $OUT/${TAG}_deep_pmc_MFMA.txt 2>&1
+# 5. other shapes / dtypes: the models' stacks at cfg2 and cfg4, fp64 on the register path, the generic kernels
+python $ROOT/tools/stack_time.py > $OUT/${TAG}_stack_time.txt 2>&1
+python $ROOT/tools/f64_time.py > $OUT/${TAG}_f64_time.txt 2>&1
+python $ROOT/tools/generic_time.py > $OUT/${TAG}_generic_time.txt 2>&1
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_*/ $OUT/${TAG}_deep_trace $OUT/${TAG}_deep_pmc   # keep the text summaries, drop the databases
 tail -c 1500 $OUT/${TAG}_bench.json; echo; head -14 $OUT/${TAG}_kernel_stats.txt; cat $OUT/${TAG}_traffic.json

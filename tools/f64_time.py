@@ -1,4 +1,6 @@
-import sys, time; sys.path.insert(0, "/root/repo")
+"""developer: fp32 vs fp64 on the register path (cfg2 size, 9->9, stride 2)"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from pointwise_amd import conv3p_op as op, synth
 dev = torch.device("cuda:0")
