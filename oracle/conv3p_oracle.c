@@ -10,9 +10,9 @@
  * (tf_conv3p_compile.sh:32: -O3, no -march, no -ffast-math): x86-64 baseline has
  * no FMA, and -ffp-contract=off keeps it that way on any host.
  *
- * PARITY STATUS: neighbour search pinned against the reference Grid template
- * (oracle/_ref, tests/test_oracle_vs_reference_grid.py); accumulation loops
- * PARITY UNPINNED (TensorFlow-bound, cannot run here).
+ * PARITY STATUS: pinned.  Neighbour search against the reference Grid template and the
+ * accumulation loops bit-for-bit against the reference's own loop text, both compiled in
+ * place into oracle/_ref (oracle/Makefile, tests/test_oracle.py).
  */
 #include "conv3p_oracle.h"
 

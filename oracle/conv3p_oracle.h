@@ -10,9 +10,14 @@
  *   - neighbour search / binning / per-bin counts (reference Grid, .cpp:138-388):
  *     PINNED against the reference's own Grid template, compiled in place from the
  *     TF-free line range of the reference file (oracle/Makefile -> oracle/_ref/).
- *   - the Compute() accumulation loops (.cpp:453-504, :608-716): PARITY UNPINNED.
- *     They are TensorFlow-bound (OpKernel/Tensor), TensorFlow is not in this image,
- *     the reference has no tests or golden vectors, so they cannot be executed here.
+ *   - the Compute() accumulation loops (.cpp:451-504, :608-716): PINNED bit-for-bit
+ *     (f32 and f64, serial) against the reference's own loop text, compiled in place
+ *     between the parts of oracle/ref_compute_driver.cpp, which supplies the locals
+ *     those lines read (sizes, pointers, `*_flat` views) in place of the TensorFlow
+ *     tensors Compute() unpacks them from (oracle/Makefile -> oracle/_ref/libref_compute_*;
+ *     tests/test_oracle.py).  The Compute() prologues (OP_REQUIRES, allocate_output) are
+ *     TensorFlow-bound and are not executed; the golden fixtures hold the reference
+ *     loops' outputs.
  *
  * All entry points return 0 on success, a negative code on invalid arguments.
  * Layouts (row-major, identical to the reference op):

@@ -6,8 +6,12 @@ Wraps
   * oracle/_ref/libref_grid_*.so the reference's own Grid template compiled in place
                                  (oracle/Makefile), when present.
 
-PARITY STATUS: neighbour search pinned by the reference Grid; the accumulation
-loops of Conv3pOp/Conv3pGradOp are PARITY UNPINNED (TensorFlow-bound).
+  * oracle/_ref/libref_compute_*.so  the reference's own Conv3pOp / Conv3pGradOp batch loops,
+                                 spliced in place around oracle/ref_compute_driver.cpp (which
+                                 supplies the locals those lines use), when present.
+
+PARITY STATUS: pinned.  Neighbour search against the reference Grid; the accumulation loops
+(y, dX, dW) bit-for-bit against the reference's own loop text (tests/test_oracle.py).
 """
 import ctypes
 import os
@@ -56,6 +60,16 @@ def ref_grid(kind="atrous"):
             h.ref_grid_lists_f64.restype = ctypes.c_long
             _REF[kind] = h
     return _REF[kind]
+
+
+def ref_compute(kind="atrous"):
+    """The reference accumulation-loop shared object: 'atrous' / 'plain' (serial, deterministic) or
+    'atrous_omp' (built like the reference CPU object, OpenMP over the batch).  None if never built."""
+    key = "compute_" + kind
+    if key not in _REF:
+        path = os.path.join(_HERE, "_ref", "libref_compute_%s.so" % kind)
+        _REF[key] = ctypes.CDLL(path) if os.path.exists(path) else None
+    return _REF[key]
 
 
 def _p(a):
@@ -193,6 +207,46 @@ def reference_grid_lists(cloud, filter_zyx, stride, voxel, kind="atrous"):
     if tot < 0:
         raise RuntimeError("ref_grid_lists rc=%d" % tot)
     return off, idx[:tot].copy(), tap[:tot].copy(), cnt
+
+
+def reference_forward(points, inp, filt, stride, voxel, kind="atrous"):
+    """Conv3p forward computed by the REFERENCE's own batch loop (tf_conv3p_atrous.cpp:451-504, or the
+    non-atrous twin for kind='plain', which ignores stride).  None when oracle/_ref was never built."""
+    h = ref_compute(kind)
+    if h is None:
+        return None
+    dt = np.dtype(points.dtype)
+    points, inp, filt = _prep(dt, points, inp, filt)
+    B, N, Cin, Cout, fz, fy, fx = _dims(points, inp, filt)
+    s = _stride(stride)
+    out = np.empty((B, N, Cout), dtype=dt)
+    ct, sfx = _CT[dt]
+    getattr(h, "ref_compute_forward_" + sfx)(_p(points), _p(inp), _p(filt), _p(s), ct(float(voxel)), B, N, Cin,
+                                             Cout, fz, fy, fx, _p(out))
+    return out
+
+
+def reference_backward(grad_out, points, inp, filt, stride, voxel, kind="atrous"):
+    """Conv3pGrad computed by the REFERENCE's own batch loop (tf_conv3p_atrous.cpp:608-716)."""
+    h = ref_compute(kind)
+    if h is None:
+        return None
+    dt = np.dtype(points.dtype)
+    grad_out, points, inp, filt = _prep(dt, grad_out, points, inp, filt)
+    B, N, Cin, Cout, fz, fy, fx = _dims(points, inp, filt)
+    assert grad_out.shape == (B, N, Cout)
+    s = _stride(stride)
+    dx = np.empty((B, N, Cin), dtype=dt)
+    dw = np.empty(filt.shape, dtype=dt)
+    ct, sfx = _CT[dt]
+    getattr(h, "ref_compute_backward_" + sfx)(_p(grad_out), _p(points), _p(inp), _p(filt), _p(s), ct(float(voxel)),
+                                              B, N, Cin, Cout, fz, fy, fx, _p(dx), _p(dw))
+    return dx, dw
+
+
+def reference_threads(kind="atrous_omp"):
+    h = ref_compute(kind)
+    return int(h.ref_compute_threads()) if h is not None else 0
 
 
 def max_threads():

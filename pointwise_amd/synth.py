@@ -76,13 +76,15 @@ def uniform_cube(B, N, seed, half=0.5, dtype=np.float32):
     return rng.uniform(-half, half, size=(B, N, 3)).astype(dtype)
 
 
-def lattice(B, N, seed, voxel=0.1, span=12, dtype=np.float32):
-    """Coordinates on integer multiples of voxel/2: every point sits on box edges / tap
+def lattice(B, N, seed, voxel=0.1, span=12, dtype=np.float32, div=2):
+    """Coordinates on integer multiples of voxel/div.  div=2: every point sits on box edges / tap
     boundaries of its neighbours, which exercises the inclusive test, the clamp, the hole test
-    and the backward's count==0 skip."""
+    and the backward's count==0 skip.  div=1 (voxel-aligned): with EVEN
+    dilated extents candidates lie exactly on the box edge AND on the border of the reference's
+    cell window (tf_conv3p_atrous.cpp:247-266), which then drops some of them by rounding."""
     rng = np.random.default_rng(seed)
     k = rng.integers(-span, span + 1, size=(B, N, 3))
-    return (k.astype(np.float64) * (np.float64(np.float32(voxel)) / 2.0)).astype(dtype)
+    return (k.astype(np.float64) * (np.float64(np.float32(voxel)) / float(div))).astype(dtype)
 
 
 def features(B, N, C, seed, points=None, dtype=np.float32):

@@ -11,10 +11,13 @@ What a fixture holds, and where each part comes from -- read this before trustin
   ref_tap,         (/root/reference/tf_ops/conv3p/tf_conv3p_atrous.cpp:138-388, or the non-atrous twin
   ref_count        tf_conv3p_grid.cpp:154-381 for kind="plain"), compiled in place by oracle/Makefile into
                    oracle/_ref/.  This is the part of the op where a one-ulp difference flips a result.
-  y, dX, dW        OUTPUT OF THE ORACLE (oracle/conv3p_oracle.c, serial build), i.e. of this repository's
-                   restatement of Conv3pOp/Conv3pGradOp::Compute (.cpp:453-504, :608-716).  The reference's
-                   Compute() is TensorFlow-bound and cannot run here, so these three arrays are regression
-                   vectors, NOT reference outputs ("parity unpinned" for the accumulation loops).
+  y, dX, dW        OUTPUT OF THE REFERENCE'S OWN CODE: the batch loops of Conv3pOp / Conv3pGradOp::Compute
+                   (tf_conv3p_atrous.cpp:451-504, :608-716, serial branch; tf_conv3p_grid.cpp:438-491, :585-689
+                   for kind="plain"), compiled in place by oracle/Makefile into oracle/_ref/libref_compute_*.so.
+                   The loop text is the reference's, unmodified; the locals it reads (sizes, pointers, the
+                   `*_flat` views) are supplied by oracle/ref_compute_driver.cpp instead of by TensorFlow
+                   tensors -- see that file.  The generator asserts that the oracle (oracle/conv3p_oracle.c)
+                   reproduces these arrays bit-for-bit before writing them.
 
 The reference repository has no tests, fixtures or golden vectors of its own.
 """
@@ -53,6 +56,13 @@ CASES = [
     ("isolated_f32", "isolated", 1, 65, 3, 9, (3, 3, 3), (2, 2, 2), "float32", 115, "atrous"),
     ("single_point_f32", "cube", 3, 1, 3, 9, (3, 3, 3), (1, 1, 1), "float32", 116, "atrous"),
     ("deep_f32", "room", 1, 256, 32, 64, (3, 3, 3), (1, 1, 1), "float32", 117, "atrous"),
+    # voxel-aligned clouds with EVEN dilated extents: candidates sit exactly on the box edge and the reference's
+    # cell window (+-n cells, n = (int)((full+1)*0.5), .cpp:247-266) drops some that pass the box test
+    ("even_lattice_f32", "vlattice", 2, 384, 3, 4, (2, 2, 2), (1, 1, 1), "float32", 118, "atrous"),
+    ("even4_lattice_f32", "vlattice", 1, 384, 2, 3, (4, 4, 4), (1, 1, 1), "float32", 119, "atrous"),
+    ("even_mixed_lattice_f64", "vlattice", 1, 300, 2, 2, (2, 3, 2), (1, 2, 2), "float64", 120, "atrous"),
+    ("scenenn_in_f32", "room", 1, 512, 12, 9, (3, 3, 3), (1, 1, 1), "float32", 121, "atrous"),
+    ("scenenn_head_f32", "room", 1, 512, 36, 41, (3, 3, 3), (1, 1, 1), "float32", 122, "atrous"),
 ]
 
 
@@ -65,6 +75,8 @@ def make_points(kind, B, N, seed, dtype):
         P = synth.room_like(B, N, seed)
     elif kind == "lattice":
         P = synth.lattice(B, N, seed, voxel=VOXEL, span=6)
+    elif kind == "vlattice":   # voxel-aligned: multiples of the voxel itself
+        P = synth.lattice(B, N, seed, voxel=VOXEL, span=8, div=1)
     elif kind == "identical":
         P = np.full((B, N, 3), 0.25, dtype=np.float32)
     elif kind == "isolated":
@@ -78,7 +90,8 @@ def make_points(kind, B, N, seed, dtype):
 
 def main():
     oracle.build()
-    if oracle.ref_grid("atrous") is None or oracle.ref_grid("plain") is None:
+    if (oracle.ref_grid("atrous") is None or oracle.ref_grid("plain") is None or
+            oracle.ref_compute("atrous") is None or oracle.ref_compute("plain") is None):
         raise SystemExit("oracle/_ref missing: run in the container that has /root/reference")
     for name, kind, B, N, Cin, Cout, fzyx, s, dts, seed, refkind in CASES:
         dt = np.dtype(dts)
@@ -90,8 +103,11 @@ def main():
         for b in range(B):
             off, idx, tap, cnt = oracle.reference_grid_lists(P[b], fzyx, s, VOXEL, kind=refkind)
             offs.append(off); idxs.append(idx); taps.append(tap); cnts.append(cnt)
-        y = oracle.forward(P, X, W, s, VOXEL)
-        dx, dw = oracle.backward(dY, P, X, W, s, VOXEL)
+        y = oracle.reference_forward(P, X, W, s, VOXEL, kind=refkind)            # the reference's own loops
+        dx, dw = oracle.reference_backward(dY, P, X, W, s, VOXEL, kind=refkind)
+        oy = oracle.forward(P, X, W, s, VOXEL)
+        odx, odw = oracle.backward(dY, P, X, W, s, VOXEL)
+        assert np.array_equal(y, oy) and np.array_equal(dx, odx) and np.array_equal(dw, odw), name
         small = np.int16 if N < 32768 else np.int32
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),

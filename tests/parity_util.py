@@ -25,6 +25,8 @@ def make_case(kind, B, N, Cin, Cout, filter_zyx=(3, 3, 3), seed=0, dtype=np.floa
         P = synth.uniform_cube(B, N, seed)
     elif kind == "lattice":
         P = synth.lattice(B, N, seed, voxel=voxel, span=6)
+    elif kind == "vlattice":   # voxel-aligned: multiples of the voxel itself
+        P = synth.lattice(B, N, seed, voxel=voxel, span=8, div=1)
     elif kind == "identical":
         P = np.full((B, N, 3), 0.25, dtype=np.float32)
     elif kind == "isolated":

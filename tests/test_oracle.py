@@ -16,13 +16,14 @@ VOX = 0.1
 
 
 def test_golden_fixtures_exist():
-    assert len(GOLDEN) >= 19
+    assert len(GOLDEN) >= 24
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_oracle_reproduces_golden(path):
-    """Neighbour lists / taps / counts produced by the REFERENCE Grid (stored in the fixture) must be
-    reproduced exactly, in the reference's visit order; y/dX/dW (oracle regression vectors) bit-for-bit."""
+    """Neighbour lists / taps / counts produced by the REFERENCE Grid and y/dX/dW produced by the REFERENCE's
+    own batch loops (both stored in the fixture, tests/golden/make_golden.py) must be reproduced exactly:
+    lists in the reference's visit order, floating-point outputs bit-for-bit."""
     g = np.load(path)
     P, X, W, dY = g["points"], g["input"], g["filter"], g["grad_out"]
     s, vox = tuple(int(v) for v in g["stride"]), float(g["voxel"])
@@ -39,6 +40,98 @@ def test_oracle_reproduces_golden(path):
     y = oracle.forward(P, X, W, s, vox)
     dx, dw = oracle.backward(dY, P, X, W, s, vox)
     assert np.array_equal(y, g["y"]) and np.array_equal(dx, g["dX"]) and np.array_equal(dw, g["dW"])
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_reference_loops_reproduce_golden_live(path):
+    """oracle/_ref/libref_compute_* (the reference's loop text compiled in place) still produces the stored
+    y/dX/dW: the fixtures really are reference output.  Skipped where _ref is absent (never on the build box)."""
+    g = np.load(path)
+    kind = str(g["ref_kind"])
+    if oracle.ref_compute(kind) is None:
+        pytest.skip("oracle/_ref not built (no /root/reference at build time)")
+    P, X, W, dY = g["points"], g["input"], g["filter"], g["grad_out"]
+    s, vox = tuple(int(v) for v in g["stride"]), float(g["voxel"])
+    y = oracle.reference_forward(P, X, W, s, vox, kind=kind)
+    dx, dw = oracle.reference_backward(dY, P, X, W, s, vox, kind=kind)
+    assert np.array_equal(y, g["y"]) and np.array_equal(dx, g["dX"]) and np.array_equal(dw, g["dW"])
+
+
+@pytest.mark.parametrize("kind", ["modelnet", "lattice", "room", "cube", "identical"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("stride", [1, 2, 3, 4])
+def test_oracle_matches_reference_loops_live(kind, dtype, stride):
+    """Fresh seeds: oracle.forward / backward (serial) are BIT-EQUAL to the reference's own accumulation loops
+    (tf_conv3p_atrous.cpp:451-504, :608-716) -- the per-term division, the c-outer / k-inner order, the
+    re-binning without inclusion re-test, the count == 0 skip."""
+    if oracle.ref_compute("atrous") is None:
+        pytest.skip("oracle/_ref not built (no /root/reference at build time)")
+    ci, co = (3, 9) if stride == 1 else (9, 9)
+    P, X, W, dY = make_case(kind, 2, 200, ci, co, seed=2000 + stride, dtype=dtype)
+    s = (stride, stride, stride)
+    y, (dx, dw) = oracle.forward(P, X, W, s, VOX), oracle.backward(dY, P, X, W, s, VOX)
+    ry = oracle.reference_forward(P, X, W, s, VOX)
+    rdx, rdw = oracle.reference_backward(dY, P, X, W, s, VOX)
+    assert np.array_equal(y, ry) and np.array_equal(dx, rdx) and np.array_equal(dw, rdw)
+
+
+@pytest.mark.parametrize("fzyx,s,ci,co", [((2, 1, 3), (1, 2, 3), 4, 5), ((5, 5, 5), (1, 1, 1), 2, 3),
+                                          ((2, 2, 2), (1, 1, 1), 3, 2), ((4, 4, 4), (2, 2, 2), 2, 2),
+                                          ((1, 1, 1), (1, 1, 1), 3, 4), ((3, 3, 3), (1, 2, 4), 5, 7),
+                                          ((3, 3, 3), (1, 1, 1), 36, 41), ((3, 3, 3), (1, 1, 1), 32, 64)])
+def test_oracle_matches_reference_loops_odd_shapes(fzyx, s, ci, co):
+    if oracle.ref_compute("atrous") is None:
+        pytest.skip("oracle/_ref not built")
+    for kind in ("cube", "lattice"):
+        for dtype in (np.float32, np.float64):
+            P, X, W, dY = make_case(kind, 1, 150, ci, co, fzyx, seed=17, dtype=dtype)
+            y, (dx, dw) = oracle.forward(P, X, W, s, VOX), oracle.backward(dY, P, X, W, s, VOX)
+            ry = oracle.reference_forward(P, X, W, s, VOX)
+            rdx, rdw = oracle.reference_backward(dY, P, X, W, s, VOX)
+            assert np.array_equal(y, ry) and np.array_equal(dx, rdx) and np.array_equal(dw, rdw)
+
+
+def test_non_atrous_reference_loops_equal_stride_one():
+    """tf_conv3p_grid.cpp's loops (the non-atrous op) give the atrous op's stride-(1,1,1) result bit-for-bit."""
+    if oracle.ref_compute("plain") is None:
+        pytest.skip("oracle/_ref not built")
+    P, X, W, dY = make_case("modelnet", 2, 300, 3, 9, seed=5)
+    a = oracle.reference_forward(P, X, W, (1, 1, 1), VOX, kind="plain")
+    b = oracle.reference_forward(P, X, W, (1, 1, 1), VOX, kind="atrous")
+    assert np.array_equal(a, b) and np.array_equal(a, oracle.forward(P, X, W, (1, 1, 1), VOX))
+    da, db = oracle.reference_backward(dY, P, X, W, (1, 1, 1), VOX, kind="plain"), oracle.reference_backward(dY, P, X, W, (1, 1, 1), VOX, kind="atrous")
+    assert np.array_equal(da[0], db[0]) and np.array_equal(da[1], db[1])
+
+
+def test_openmp_reference_build_matches_serial():
+    """The reference built like its CPU object (-fopenmp -DCONV_OPENMP; what bench.py times as the CPU
+    baseline): y and dX bit-equal to the serial build, dW up to the order of the per-thread partials."""
+    if oracle.ref_compute("atrous_omp") is None:
+        pytest.skip("oracle/_ref not built")
+    P, X, W, dY = make_case("modelnet", 4, 256, 9, 9, seed=61)
+    s = (2, 2, 2)
+    y = oracle.reference_forward(P, X, W, s, VOX, kind="atrous_omp")
+    dx, dw = oracle.reference_backward(dY, P, X, W, s, VOX, kind="atrous_omp")
+    assert np.array_equal(y, oracle.forward(P, X, W, s, VOX))
+    odx, odw = oracle.backward(dY, P, X, W, s, VOX)
+    assert np.array_equal(dx, odx) and rel_err(dw, odw) < 1e-5
+
+
+def test_even_extent_cell_window_drops_box_edge_candidates():
+    """On voxel-aligned clouds with EVEN dilated extents the reference's cell window (.cpp:247-266) rejects
+    candidates that pass the inclusive box test: the fixtures must contain such cases, so that an
+    all-pairs implementation cannot pass them."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "even_lattice_f32.npz"))
+    P, vox = g["points"], float(np.float32(g["voxel"]))   # T voxel_size: the float nearest 0.1 (.cpp:444)
+    ref_pairs = int(g["ref_pairs_per_cloud"].sum())
+    brute = 0
+    for b in range(P.shape[0]):
+        p = P[b]
+        lo = (p.astype(np.float64) - 1.0 * vox).astype(np.float32)     # full = 2: half extent = 1 voxel
+        hi = (p.astype(np.float64) + 1.0 * vox).astype(np.float32)
+        inside = np.all((p[None, :, :] >= lo[:, None, :]) & (p[None, :, :] <= hi[:, None, :]), axis=2)
+        brute += int(inside.sum())
+    assert brute > ref_pairs, (brute, ref_pairs)
 
 
 @pytest.mark.parametrize("kind", ["modelnet", "lattice", "room", "cube", "identical"])
