@@ -1,8 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- conv3p forward+backward throughput of the pointcnn2_acsd conv3p stack on MI355X.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run,
-one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 with WORLD_SIZE unset (plain `python bench.py --gpus 8`): bench.py re-executes itself through
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU;
+  launched by torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
+  Fewer than N visible devices, or WORLD_SIZE != N, is an error (never a silent n_gpus = 1 run).
 
 A "step" is one pass of the hot path over one batch of synthetic input: forward and backward of the four conv3p
 layers of the classification model (3->9 s1, 9->9 s2, 9->9 s3, 9->9 s4, SELU in between;
@@ -10,18 +13,35 @@ layers of the classification model (3->9 s1, 9->9 s2, 9->9 s3, 9->9 s4, SELU in 
 (BASELINE.json configs[1]; weak scaling, configs[2] = 8 x 32), followed for N>1 by the one fused RCCL all-reduce of
 the weight gradients.  Inputs are resident in HBM before the timed region.  metric = B*N*n_gpus / t_step.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel (by HIP-event time, measured in a second, instrumented run of the same K steps
-                on the same stream): algorithmic bytes per launch / average launch duration vs 8 TB/s HBM
-  cpu_baseline  the oracle (CPU restatement of the reference op, OpenMP over the batch as the reference does)
-                timed on this host's cores on a bounded sample of the same workload -- rank 0, N=1 only
-  parity        max |delta| of y / dX / dW between the HIP path and the CPU oracle on a 2-cloud sample
+Extra objects on the JSON line (rank 0; everything except `roofline` only at N=1):
+  roofline           dominant kernel of the headline step (by HIP-event time, measured live in a second,
+                     instrumented run of the same K steps on the same streams): algorithmic bytes per launch /
+                     average launch duration vs 8 TB/s.  avg_launch_us is measured WITH the side-stream overlap the
+                     headline uses (other kernels share the CUs); avg_launch_us_isolated comes from a third pass
+                     with no side stream at all -- `achieved` / `frac` use the overlapped figure (the conservative one).
+  cpu_baseline       the REFERENCE's own Conv3p / Conv3pGrad batch loops (oracle/_ref/libref_compute_atrous_omp.so:
+                     tf_conv3p_atrous.cpp compiled in place with the reference's flags -O3 -fopenmp -DCONV_OPENMP)
+                     timed on this host's cores on a bounded sample of the same workload; kind = "reference".
+                     Falls back to the oracle's C restatement (kind = "port") where oracle/_ref is absent.
+  cpu_baseline_cfg1  BASELINE config 1: B=1, N=2048, 3->9, stride 1, forward only, serial reference loops.
+  stateless_ms_per_step   the same cfg2 step through the stateless C entry points exactly as the TF shim
+                     (integration/tf_conv3p_shim.cc) calls them: conv3p_forward_f32 / conv3p_backward_f32 per op, no
+                     cache, no hints, no prefetch, SELU as its own op -- what an unmodified TF graph would get.
+  other_configs      cfg4 (S3DIS scene_seg stack, B=16 x N=4096, 5 layers) and the cfg5 per-GPU shard (B=16 x N=8192,
+                     one 128->256 layer): ms/step, Mpoints/s and a roofline each (cfg4 HBM, 1376 B/point;
+                     cfg5 fp32 MFMA, USEFUL flops = 5.31 MFLOP/point = 3 x 2*27*Cin*Cout, vs 157.3 TFLOP/s).
+  parity             max |delta| of y / dX / dW between the HIP path and the CPU oracle on a 2-cloud sample
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # CPU legs: no spinning between the short parallel regions
 
 import numpy as np
 import torch
@@ -35,6 +55,7 @@ B_PER_GPU = 32
 N_POINTS = 2048
 C_IN = 3
 HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
 def algorithmic_bytes(kind, B, N, cin, cout):
@@ -51,41 +72,187 @@ def algorithmic_bytes(kind, B, N, cin, cout):
     return 0
 
 
+def stack_bytes_per_point(layers):
+    """fwd+bwd = 24 + 12*Cin + 8*Cout bytes per point and layer."""
+    return sum(24 + 12 * ci + 8 * co for ci, co, _ in layers)
+
+
+def read_kernel_times(lib):
+    kinds = {}
+    for k in range(lib.conv3p_profile_kinds()):
+        n, ms = ctypes.c_uint64(0), ctypes.c_double(0.0)
+        lib.conv3p_profile_read(k, ctypes.byref(n), ctypes.byref(ms))
+        if n.value:
+            kinds[lib.conv3p_profile_name(k).decode()] = (n.value, ms.value)
+    lib.conv3p_profile_reset()
+    return kinds
+
+
+def profile_steps(lib, dev, step, steps):
+    """Per-kernel HIP-event timing of `steps` steps (instrumented; never the timed region)."""
+    lib.conv3p_profile_reset()
+    lib.conv3p_profile_enable(1)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    lib.conv3p_profile_enable(0)
+    return read_kernel_times(lib)
+
+
+def timed(dev, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+# ------------------------------------------------------------------------------------------- CPU legs
+def _oracle_pass(fwd, bwd, P, X, ups, filters, layers):
+    acts, x = [], X
+    for li in range(4):
+        s = layers[li][2]
+        x = stack.selu_numpy(fwd(P, x, filters[li], (s, s, s)))
+        acts.append(x)
+    carry, dws = None, [None] * 4
+    for li in (3, 2, 1, 0):
+        s = layers[li][2]
+        g = ups[li] if carry is None else ups[li] + carry
+        g = stack.selu_grad_numpy(acts[li], g)
+        x_in = acts[li - 1] if li > 0 else X
+        carry, dws[li] = bwd(g, P, x_in, filters[li], (s, s, s))
+    return acts, carry, dws
+
+
 def cpu_baseline(points_np, feats_np, st, ups_np, budget_s=12.0):
-    """Time the CPU oracle on the same stack; also returns its outputs for the parity numbers."""
+    """Time the reference CPU loops on the same stack; also returns the serial oracle's outputs for parity."""
     from oracle import oracle                      # checker only; never on the product path
-    threads = max(1, min(points_np.shape[0], os.cpu_count() or 1))
     filters = [f.detach().cpu().numpy() for f in st.filters]
-
-    def one_pass(P, X, ups, nthreads):
-        acts, x = [], X
-        for li in range(4):
-            s = st.layers[li][2]
-            x = stack.selu_numpy(oracle.forward(P, x, filters[li], (s, s, s), stack.VOXEL, nthreads=nthreads))
-            acts.append(x)
-        carry, dws = None, [None] * 4
-        for li in (3, 2, 1, 0):
-            s = st.layers[li][2]
-            g = ups[li] if carry is None else ups[li] + carry
-            g = stack.selu_grad_numpy(acts[li], g)
-            x_in = acts[li - 1] if li > 0 else X
-            carry, dws[li] = oracle.backward(g, P, x_in, filters[li], (s, s, s), stack.VOXEL, nthreads=nthreads)
-        return acts, carry, dws
-
+    have_ref = oracle.ref_compute("atrous_omp") is not None
+    if have_ref:
+        cores = oracle.reference_threads()         # Conv3pGradOp forces hardware_concurrency() threads (.cpp:611-619)
+        fwd = lambda P, x, w, s: oracle.reference_forward(P, x, w, s, stack.VOXEL, kind="atrous_omp")
+        bwd = lambda g, P, x, w, s: oracle.reference_backward(g, P, x, w, s, stack.VOXEL, kind="atrous_omp")
+        kind = "reference"
+    else:
+        cores = max(1, min(points_np.shape[0], os.cpu_count() or 1))
+        fwd = lambda P, x, w, s: oracle.forward(P, x, w, s, stack.VOXEL, nthreads=cores)
+        bwd = lambda g, P, x, w, s: oracle.backward(g, P, x, w, s, stack.VOXEL, nthreads=cores)
+        kind = "port"
     reps, t_total = 0, 0.0
     while t_total < budget_s and reps < 50:
         t0 = time.perf_counter()
-        one_pass(points_np, feats_np, ups_np, threads)
+        _oracle_pass(fwd, bwd, points_np, feats_np, ups_np, filters, st.layers)
         t_total += time.perf_counter() - t0
         reps += 1
     pts = points_np.shape[0] * points_np.shape[1]
     value = pts * reps / t_total / 1e6
     # serial (deterministic) oracle on 2 clouds for the parity numbers
-    ref = one_pass(points_np[:2], feats_np[:2], [u[:2] for u in ups_np], 1)
-    return {"value": round(value, 4), "unit": "Mpoints/s", "cores": threads, "kind": "port",
-            "sample": "%d repetitions of the full workload (B=%d, N=%d, 4-layer stack fwd+bwd), OpenMP over "
-                      "the batch like the reference, %.1f s of CPU time" % (reps, points_np.shape[0],
-                                                                            points_np.shape[1], t_total)}, ref
+    sf = lambda P, x, w, s: oracle.forward(P, x, w, s, stack.VOXEL)
+    sb = lambda g, P, x, w, s: oracle.backward(g, P, x, w, s, stack.VOXEL)
+    ref = _oracle_pass(sf, sb, points_np[:2], feats_np[:2], [u[:2] for u in ups_np], filters, st.layers)
+    what = ("the reference's own batch loops (tf_conv3p_atrous.cpp:451-504, :608-716 compiled in place, "
+            "-O3 -fopenmp -DCONV_OPENMP)") if have_ref else "the oracle's C restatement"
+    base = {"value": round(value, 4), "unit": "Mpoints/s", "cores": cores, "kind": kind,
+            "sample": "%d repetitions of the full workload (B=%d, N=%d, 4-layer stack fwd+bwd) through %s, OpenMP "
+                      "over the batch, %.1f s of CPU time" % (reps, points_np.shape[0], points_np.shape[1], what,
+                                                              t_total)}
+    # BASELINE config 1: one cloud, first layer, forward only, serial
+    P1, W1 = points_np[:1], filters[0]
+    serial_ref = oracle.ref_compute("atrous") is not None
+    f1 = (lambda: oracle.reference_forward(P1, P1, W1, (1, 1, 1), stack.VOXEL)) if serial_ref else \
+        (lambda: oracle.forward(P1, P1, W1, (1, 1, 1), stack.VOXEL))
+    f1()
+    best, n1, t1 = 1e9, 0, 0.0
+    while t1 < 1.5 and n1 < 200:
+        t0 = time.perf_counter()
+        f1()
+        dt = time.perf_counter() - t0
+        best, n1, t1 = min(best, dt), n1 + 1, t1 + dt
+    cfg1 = {"value": round(points_np.shape[1] / best / 1e6, 4), "unit": "Mpoints/s", "ms": round(best * 1e3, 4),
+            "cores": 1, "kind": "reference" if serial_ref else "port",
+            "sample": "BASELINE config 1: B=1, N=2048, 3->9, stride 1, forward only, serial; best of %d calls" % n1}
+    return base, cfg1, ref
+
+
+# ------------------------------------------------------------------------------------------- other configs
+def cfg4_report(lib, dev, steps=20, warmup=5):
+    """S3DIS scene_seg stack (pointcnn_scene_seg_acsd.py:51-57): B=16, N=4096, C_in=9, 13 classes."""
+    B, N, cin, ncls = 16, 4096, 9, 13
+    Ps = [torch.from_numpy(synth.room_like(B, N, 40 + i)).to(dev) for i in range(3)]
+    Xs = [torch.from_numpy(synth.features(B, N, cin, 50 + i, points=p.cpu().numpy())).to(dev) for i, p in enumerate(Ps)]
+    st = stack.Conv3pStack(cin, ncls, device=dev, seed=3)
+    ups = [torch.from_numpy(synth.upstream_grad(B, N, ncls, 60)).to(dev)]
+    ctr = [0]
+
+    def step():
+        i = ctr[0] % 3
+        ctr[0] += 1
+        st.forward(Ps[i], Xs[i])
+        st.prefetch(Ps[(i + 1) % 3])
+        st.backward(ups)
+
+    dt = timed(dev, step, steps, warmup)
+    bpp = stack_bytes_per_point(st.layers)
+    achieved = bpp * B * N / dt / 1e9
+    kinds = profile_steps(lib, dev, step, 5)
+    del st
+    return {"workload": "cfg4 S3DIS scene_seg-shaped: B=16 x N=4096 room blocks, C_in=9, conv3p stack 9->9 s1..s4 + 36->13 "
+                        "s1 (+SELU), forward+backward, a different batch every step",
+            "ms_per_step": round(dt * 1e3, 4), "value": round(B * N / dt / 1e6, 3), "unit": "Mpoints/s",
+            "roofline": {"bound": "hbm", "scope": "whole step", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "bytes_per_point": bpp},
+            "kernel_ms_per_step": {k: round(v[1] / 5, 4) for k, v in kinds.items()}}
+
+
+def cfg5_report(lib, dev, steps=5, warmup=2):
+    """cfg5 per-GPU shard: B=16, N=8192 SceneNN-shaped rooms, ONE 128->256 layer, stride 1, forward+backward,
+    geometry rebuilt every step (two alternating batches)."""
+    B, N, ci, co = 16, 8192, 128, 256
+    t = lambda a: torch.from_numpy(a).to(dev)
+    Ps = [t(synth.room_like(B, N, 7 + i, extent=(2.4, 2.4, 3.0))) for i in range(2)]
+    X = t(synth.features(B, N, ci, 8, points=Ps[0].cpu().numpy()))
+    dY = t(synth.upstream_grad(B, N, co, 9))
+    W = t(synth.filter_weights(3, 3, 3, ci, co, 5))
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
+    ctr = [0]
+
+    def step():
+        P = Ps[ctr[0] % 2]
+        ctr[0] += 1
+        op.conv3p(P, X, W, (1, 1, 1), stack.VOXEL, cache=cache)
+        op.conv3p_grad(dY, P, X, W, (1, 1, 1), stack.VOXEL, cache=cache, points_unchanged=True)
+
+    dt = timed(dev, step, steps, warmup)
+    useful = 3 * 2 * 27 * ci * co * B * N            # fwd + dX + dW, dense-equivalent (SURVEY.md 8(d))
+    achieved = useful / dt / 1e12
+    kinds = profile_steps(lib, dev, step, 2)
+    del cache
+    return {"workload": "cfg5 per-GPU shard: B=16 x N=8192 SceneNN-shaped rooms, one conv3p layer 128->256, stride 1, "
+                        "forward+backward, geometry rebuilt every step",
+            "ms_per_step": round(dt * 1e3, 3), "value": round(B * N / dt / 1e6, 3), "unit": "Mpoints/s",
+            "roofline": {"bound": "mfma", "scope": "whole step", "achieved": round(achieved, 2),
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                         "flops_per_point": 3 * 2 * 27 * ci * co,
+                         "note": "useful (dense-equivalent) flops; the matrix instructions ISSUED are more (selection "
+                                 "products, tile padding) -- see profiles/ for SQ_INSTS_MFMA"},
+            "kernel_ms_per_step": {k: round(v[1] / 2, 4) for k, v in kinds.items()}}
+
+
+# ------------------------------------------------------------------------------------------- launch plumbing
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: run the same command one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -93,18 +260,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip other_configs / stateless / isolated passes")
     ap.add_argument("--serial", action="store_true",
                     help="developer: no side stream at all (clean per-kernel durations under rocprofv3)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not enqueue the next batch's neighbour search under the current batch's backward")
     args = ap.parse_args()
 
-    rank, world, local = distributed.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
+    rank, world, local = distributed.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     lib = _lib.load()
@@ -135,18 +309,22 @@ def main():
 
     prefetch = not (args.no_prefetch or args.serial)
 
-    def step():
-        i = counter[0] % NBATCH
-        counter[0] += 1
-        st.forward(tPs[i], tXs[i])
-        if prefetch:
-            # the next batch's geometry (1 sort + 4 searches) goes to the side stream now and runs under this
-            # batch's backward, as a data-loader-fed training loop would do.  Every step still performs exactly
-            # one full geometry build, one forward and one backward inside the timed region.
-            st.prefetch(tPs[(i + 1) % NBATCH])
-        dx, fused = st.backward(ups)
-        distributed.allreduce_weight_grads(fused)
-        return dx, fused
+    def make_step(stk, pre):
+        def step():
+            i = counter[0] % NBATCH
+            counter[0] += 1
+            stk.forward(tPs[i], tXs[i])
+            if pre:
+                # the next batch's geometry (1 sort + 4 searches) goes to the side stream now and runs under this
+                # batch's backward, as a data-loader-fed training loop would do.  Every step still performs exactly
+                # one full geometry build, one forward and one backward inside the timed region.
+                stk.prefetch(tPs[(i + 1) % NBATCH])
+            dx, fused = stk.backward(ups)
+            distributed.allreduce_weight_grads(fused)
+            return dx, fused
+        return step
+
+    step = make_step(st, prefetch)
 
     # CPython's full (generation-2) collection walks every object torch and numpy created at import: a ~40 ms
     # host pause that hits once every few thousand allocations, i.e. somewhere inside a 100-step timed region
@@ -167,20 +345,18 @@ def main():
     elapsed = distributed.max_over_ranks(time.perf_counter() - t0, dev)
 
     # ---- per-kernel HIP-event timing of the same K steps (instrumented, not the timed region) ----
-    lib.conv3p_profile_reset()
-    lib.conv3p_profile_enable(1)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    lib.conv3p_profile_enable(0)
-    import ctypes
-    kinds = {}
-    for k in range(lib.conv3p_profile_kinds()):
-        n, ms = ctypes.c_uint64(0), ctypes.c_double(0.0)
-        lib.conv3p_profile_read(k, ctypes.byref(n), ctypes.byref(ms))
-        if n.value:
-            kinds[lib.conv3p_profile_name(k).decode()] = (n.value, ms.value)
-    lib.conv3p_profile_reset()
+    kinds = profile_steps(lib, dev, step, args.steps)
+    extra = world == 1 and not args.no_extra
+    kinds_iso = None
+    if extra and prefetch:
+        # the same steps with no side stream at all: kernels run alone, one after the other
+        st_iso = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=False)
+        st_iso.prepare(B_PER_GPU, N_POINTS)
+        step_iso = make_step(st_iso, False)
+        for _ in range(3):
+            step_iso()
+        kinds_iso = profile_steps(lib, dev, step_iso, min(args.steps, 20))
+        del st_iso
 
     out = None
     if rank == 0:
@@ -211,7 +387,19 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "avg_launch_us": round(avg_s * 1e6, 2), "bytes_per_launch": int(bytes_per_launch),
+                        "avg_launch_us_note": "measured with the headline's side-stream overlap (other kernels share "
+                                              "the CUs); achieved/frac use this figure",
                         "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in kinds.items()}}
+            if kinds_iso and dom in kinds_iso:
+                ni, msi = kinds_iso[dom]
+                roofline["avg_launch_us_isolated"] = round(msi / ni * 1e3, 2)
+                roofline["frac_isolated"] = round(bytes_per_launch / (msi / ni * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                nst = min(args.steps, 20)
+                roofline["kernel_ms_per_step_isolated"] = {k: round(v[1] / nst, 4) for k, v in kinds_iso.items()}
+            bpp = stack_bytes_per_point(st.layers)
+            roofline["whole_step"] = {"bytes_per_point": bpp,
+                                      "achieved": round(bpp * total_pts / world / (elapsed / args.steps) / 1e9, 2),
+                                      "frac": round(bpp * total_pts / world / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
         out = {"metric": "conv3p fwd+bwd Mpoints/s", "value": round(total_pts / (elapsed / args.steps) / 1e6, 3),
                "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "host_enqueue_ms_per_step": round(host_ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
@@ -225,9 +413,19 @@ def main():
                           "global_batch": B_PER_GPU * world, "points_per_cloud": N_POINTS,
                           "parallelism": "dp%d" % world},
                "roofline": roofline}
+        if extra:
+            # the drop-in boundary as the TF shim drives it: stateless ops, SELU as separate ops
+            st_plain = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, use_cache=False)
+            step_plain = make_step(st_plain, False)
+            dt_plain = timed(dev, step_plain, min(args.steps, 20), 3)
+            out["stateless_ms_per_step"] = round(dt_plain * 1e3, 4)
+            out["stateless_value"] = round(total_pts / dt_plain / 1e6, 3)
+            del st_plain
+            out["other_configs"] = {"cfg4": cfg4_report(lib, dev), "cfg5_shard": cfg5_report(lib, dev)}
         if world == 1 and not args.no_cpu:
-            base, ref = cpu_baseline(P, P.copy(), st, ups_np)
+            base, cfg1, ref = cpu_baseline(P, P.copy(), st, ups_np)
             out["cpu_baseline"] = base
+            out["cpu_baseline_cfg1"] = cfg1
             # parity of the HIP path against the oracle on the first two clouds
             acts = st.forward(tP[:2].contiguous(), tX[:2].contiguous())
             dx, fused = st.backward([u[:2].contiguous() for u in ups])

@@ -17,7 +17,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libconv3p_hip.so")
-SOURCES = ["conv3p_abi.hip", "conv3p_kernels.hpp", "conv3p_device.hpp"]
+def sources():
+    """Every file the library is compiled from: the one translation unit plus all headers beside it."""
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+
+
 HEADER = os.path.join(os.path.dirname(HERE), "include", "conv3p.h")
 ARCH = "gfx950"
 
@@ -29,7 +33,7 @@ def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    deps = [os.path.join(CSRC, s) for s in sources()] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

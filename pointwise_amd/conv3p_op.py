@@ -258,6 +258,7 @@ def cache_prepare(points, filter_zyx, stride, voxel_size, cache, points_unchange
     fz, fy, fx = [int(v) for v in filter_zyx]
     if not cache.fits(B, N, points.dtype, dev, fz * fy * fx, 0, 0):
         raise Conv3pInvalidArgument("neighbour cache does not fit these clouds")
+    points = points.contiguous()
     with torch.cuda.device(dev):
         st = stream if stream is not None else torch.cuda.current_stream(dev)
         _call(getattr(lib, "conv3p_cache_prepare_" + sfx), points.data_ptr(), ctypes.cast(s3, ctypes.c_void_p),

@@ -114,7 +114,9 @@ template <typename T> Stencil<T> make_stencil(const Dims &d, const int32_t *stri
         st.shift[a] = (float)((1.0 - 1.0 / (double)st.step[a]) * 0.5 - 0.5);
         st.halfw[a] = (float)(0.5 / (double)st.step[a]);
         st.mmax[a] = (float)(st.ext[a] - 1);
+        st.reach[a] = (int)((st.full[a] + 1) * 0.5);              // .cpp:247-249
     }
+    st.window = ((st.full[0] & 1) == 0 || (st.full[1] & 1) == 0 || (st.full[2] & 1) == 0) ? 1 : 0;
     st.ntap = d.ntap;
     st.voxel = voxel;
     return st;
@@ -159,6 +161,7 @@ template <typename T> struct Layout {
     uint32_t *version;
     PointRec<T> *pts;
     T *boxes;
+    T *cmin;   // [B][3] origin of the reference's uniform grid (stencils with an even dilated extent only)
     // per slot
     struct Slot {
         uint32_t *built_version, *rebuilt, *cursor;
@@ -200,8 +203,10 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
     L.version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
     L.pts = reinterpret_cast<PointRec<T> *>(take(sizeof(PointRec<T>) * (size_t)B * ntiles * kTile));
     L.boxes = reinterpret_cast<T *>(take(sizeof(T) * (size_t)B * ntiles * 6));
+    L.cmin = reinterpret_cast<T *>(take(sizeof(T) * (size_t)B * 3));
     size_t ppc = (size_t)N * (size_t)pairs_per_point;
     if ((size_t)B * ppc > 0xFFFFFFF0ull) ppc = B ? 0xFFFFFFF0ull / (size_t)B : 0;
+    if (ppc > 0x7FFFFFFFull) ppc = 0x7FFFFFFFull;   // headroom for the allocator's transient overshoot (search_tile P2)
     L.pairs_per_cloud = (uint32_t)ppc;
     L.slot.resize(nslots);
     L.nclouds = B;
@@ -346,6 +351,21 @@ template <typename T> int run_prep(const T *points, const Call<T> &c)
     return hip_ok();
 }
 
+template <typename T> size_t search_lds_bytes(const Stencil<T> &st, int gtiles)
+{
+    return lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) + 64 * 3 * 4 +
+           a16((size_t)gtiles * 64 * 8) + a16((size_t)gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
+           a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
+}
+
+// grid origin of every cloud, for stencils whose candidate window can decide (even dilated extents)
+template <typename T> int run_cloud_min(const T *points, const Call<T> &c)
+{
+    if (!c.st.window) return CONV3P_OK;
+    hipLaunchKernelGGL(cloud_min_kernel<T>, dim3((unsigned)c.d.B), dim3(256), 0, c.s, points, c.d.N, c.L.cmin);
+    return hip_ok();
+}
+
 // search (+ finalise when pair lists are wanted).  count: where the populations go.
 template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
@@ -353,18 +373,19 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) +
-                       a16((size_t)c.L.gtiles * 64 * 8) + a16((size_t)c.L.gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
-                       a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
+    const size_t lds = search_lds_bytes(st, c.L.gtiles);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;   // very large filters (> ~340 taps): populations alone exceed LDS
     const BlockMap bm = make_blockmap(d);
     {
         Scope sc(K_SEARCH, c.s);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(search_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(search_kernel<T>, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes, st, d.N,
-                           d.ntiles, c.L.gtiles, c.L.ngroups, bm, count, with_pairs ? S.pairs : nullptr, c.cc,
-                           S.segs, S.qsegs);
+        auto launch = [&](auto kern, const T *cmin) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes, st, d.N, d.ntiles,
+                               c.L.gtiles, c.L.ngroups, bm, count, with_pairs ? S.pairs : nullptr, c.cc, S.segs, S.qsegs,
+                               cmin);
+        };
+        if (st.window) launch(search_kernel<T, true>, c.L.cmin);
+        else launch(search_kernel<T, false>, static_cast<const T *>(nullptr));
     }
     TRY(hip_ok());
     if (with_pairs) {
@@ -393,7 +414,7 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, d.Cin, d.Cout,
-                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0);
+                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0, st.window ? c.L.cmin : nullptr);
     return hip_ok();
 }
 
@@ -418,7 +439,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
-                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots);
+                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr);
     return hip_ok();
 }
 
@@ -676,6 +697,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     c.act = act;
     TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
     TRY(run_prep<T>(points, c));
+    TRY(run_cloud_min<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) {                                                                   \
@@ -712,6 +734,7 @@ int prepare_impl(const T *points, const int32_t *stride, T voxel, int B, int N, 
     Call<T> c;
     TRY(begin_call<T>(c, d, stride, voxel, 0, wh, static_cast<hipStream_t>(stream)));
     TRY(run_prep<T>(points, c));
+    TRY(run_cloud_min<T>(points, c));
     return run_search<T>(c, c.L.slot[c.slot].count, true);
 }
 
@@ -731,6 +754,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
     SearchJobs<T> jobs;
     int njobs = 0;
     size_t lds = 0;
+    bool any_window = false;
     Call<T> c;
     for (int k = 0; k < K; ++k) {
         TRY(begin_call<T>(c, d, strides + 3 * k, voxel, 0, wh, s));
@@ -739,9 +763,9 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         if (c.skip_search) continue;
         const Stencil<T> &st = c.st;
         const auto &S = c.L.slot[c.slot];
-        const size_t l = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) +
-                         a16((size_t)c.L.gtiles * 64 * 8) + a16((size_t)c.L.gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
-                         a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
+        TRY(run_cloud_min<T>(points, c));
+        any_window |= st.window != 0;
+        const size_t l = search_lds_bytes(st, c.L.gtiles);
         if (l > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
         lds = l > lds ? l : lds;
         SearchJob<T> &j = jobs.job[njobs++];
@@ -756,10 +780,13 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
     const BlockMap bm = make_blockmap(c.d);
     {
         Scope sc(K_SEARCH, s);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(search_multi_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(search_multi_kernel<T>, dim3(grid_of(bm), njobs), dim3(256), lds, s, c.L.pts, c.L.boxes,
-                           c.d.N, c.d.ntiles, c.L.gtiles, c.L.ngroups, bm, jobs);
+        auto launch = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(grid_of(bm), njobs), dim3(256), lds, s, c.L.pts, c.L.boxes, c.d.N, c.d.ntiles,
+                               c.L.gtiles, c.L.ngroups, bm, jobs, c.L.cmin);
+        };
+        if (any_window) launch(search_multi_kernel<T, true>);    // window replication is a no-op for odd extents
+        else launch(search_multi_kernel<T, false>);
     }
     TRY(hip_ok());
     {
@@ -797,6 +824,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     c.addend = addend;
     TRY(begin_call<T>(c, d, stride, voxel, backward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
     TRY(run_prep<T>(points, c));
+    TRY(run_cloud_min<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     int rc = CONV3P_ERR_UNSUPPORTED;
     int nslots = (int)grid_of(make_blockmap(d));
@@ -851,6 +879,7 @@ int count_impl(const T *points, const int32_t *stride, T voxel, int B, int N, in
     const Where wh{ws, ws_bytes, false, 1, d.ntap, 0, 0, 0};   // populations only: no pair storage
     TRY(begin_call<T>(c, d, stride, voxel, 0, wh, s));
     TRY(run_prep<T>(points, c));
+    TRY(run_cloud_min<T>(points, c));
     return run_search<T>(c, count, false);
 }
 

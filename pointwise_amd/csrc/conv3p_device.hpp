@@ -64,6 +64,8 @@ template <typename T> struct Stencil {
     int full[3];     // dilated extent (ext-1)*step+1            (.cpp:235-237)
     int ntap;        // fx*fy*fz
     int maxfull;     // max(full[a]); row length of the tap lookup table
+    int reach[3];    // the reference grid's candidate window, +-n cells per axis: n = (int)((full+1)*0.5)  (.cpp:247-249)
+    int window;      // != 0 when some full[a] is even: only then can the window reject a point inside the box
     T voxel;
     double half[3];  // (double)full * 0.5 * (double)voxel        (.cpp:240)
     // pre-filter constants (fp32, see scan_tile)
@@ -181,6 +183,42 @@ template <typename T> struct Query {
     int orig;           // original index inside the cloud, -1 for padding lanes
 };
 
+// Window mode only (stencils with an even dilated extent): the cloud's grid origin (.cpp:163-177) and the
+// centre's grid cell (.cpp:251-253).  Kept out of Query so that the common kernels carry no extra live state.
+template <typename T> struct Window {
+    T vmin[3];
+    int cell[3];
+};
+
+// Grid cell of coordinate v (cell edge = voxel, origin vmin): IEEE divide + truncate (.cpp:192-194, :251-253).
+template <typename T> __device__ __forceinline__ int grid_cell(T v, T vmin, T voxel) { return (int)((v - vmin) / voxel); }
+
+// The reference only visits candidates in the cells centre +- reach (.cpp:260-266).  For odd dilated extents that
+// window is half a cell wider than the filter box and never decides; for EVEN extents its border coincides with
+// the box edge, and on voxel-aligned data rounding of the two cell indices drops candidates that pass the
+// inclusive box test.  Replicated exactly: same origin, same division, same truncation.
+template <typename T>
+__device__ __forceinline__ bool outside_window(T vx, T vy, T vz, const T *vmin, const int *ccell, const Stencil<T> &st)
+{
+    const int dx = grid_cell(vx, vmin[0], st.voxel) - ccell[0];
+    const int dy = grid_cell(vy, vmin[1], st.voxel) - ccell[1];
+    const int dz = grid_cell(vz, vmin[2], st.voxel) - ccell[2];
+    return (dx > st.reach[0]) | (dx < -st.reach[0]) | (dy > st.reach[1]) | (dy < -st.reach[1]) |
+           (dz > st.reach[2]) | (dz < -st.reach[2]);
+}
+
+template <typename T>
+__device__ __forceinline__ void make_window(Window<T> &w, const PointRec<T> &me, const Stencil<T> &st,
+                                            const T *__restrict__ cloud_min)
+{
+#pragma unroll
+    for (int a = 0; a < 3; ++a) w.vmin[a] = cloud_min[a];
+    const bool valid = me.idx >= 0;
+    w.cell[0] = valid ? grid_cell(me.x, w.vmin[0], st.voxel) : 0;
+    w.cell[1] = valid ? grid_cell(me.y, w.vmin[1], st.voxel) : 0;
+    w.cell[2] = valid ? grid_cell(me.z, w.vmin[2], st.voxel) : 0;
+}
+
 template <typename T>
 __device__ __forceinline__ void make_query(Query<T> &q, const PointRec<T> &me, const Stencil<T> &st)
 {
@@ -244,11 +282,12 @@ __device__ __forceinline__ int axis_tap(T v, T lo, T voxel, int full, const int1
 // test (.cpp:277) followed by the tap computation (.cpp:280-290).  Returns the tap or -1.
 template <typename T>
 __device__ __forceinline__ int exact_tap(const PointRec<T> &v, const Query<T> &q, const Stencil<T> &st,
-                                         const int16_t *tapmap)
+                                         const int16_t *tapmap, const Window<T> *win = nullptr)
 {
     const bool out = (v.x < q.lo[0]) | (v.x > q.hi[0]) | (v.y < q.lo[1]) | (v.y > q.hi[1]) |
                      (v.z < q.lo[2]) | (v.z > q.hi[2]);
     if (out) return -1;
+    if (win != nullptr && outside_window(v.x, v.y, v.z, win->vmin, win->cell, st)) return -1;   // .cpp:260-266
     const int tx = axis_tap(v.x, q.lo[0], st.voxel, st.full[0], tapmap);
     const int ty = axis_tap(v.y, q.lo[1], st.voxel, st.full[1], tapmap + st.maxfull);
     const int tz = axis_tap(v.z, q.lo[2], st.voxel, st.full[2], tapmap + 2 * st.maxfull);
@@ -405,7 +444,7 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
                                                   const T *__restrict__ cloud_box, int ntiles,
                                                   const Query<T> &q, const Stencil<T> &st,
                                                   const int16_t *tapmap, float *soa, int first, int stride,
-                                                  OnHit &&on_hit)
+                                                  OnHit &&on_hit, const Window<T> *win = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const bool qvalid = q.orig >= 0;
@@ -425,7 +464,7 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
             if (!qvalid) m0 = m1 = 0;
             for_each_bit(m0, m1, [&](int c) {
                 const PointRec<T> v = tile[c];
-                const int f = exact_tap(v, q, st, tapmap);
+                const int f = exact_tap(v, q, st, tapmap, win);
                 if (f >= 0) on_hit(v, f);
             });
         }

@@ -300,6 +300,36 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
 
 
 // ---------------------------------------------------------------------------------
+// Origin of the reference's uniform grid, per cloud: vmin = min(1e6f, min over the points) per axis, evaluated
+// in T with std::min's "keep unless smaller" rule, so a NaN coordinate is ignored (.cpp:163-177).  Needed only by
+// stencils with an even dilated extent (Stencil::window); launched with those searches only.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cloud_min_kernel(const T *__restrict__ points, int N, T *__restrict__ cmin)
+{
+    __shared__ T red[3][4];
+    const T *cloud = points + (size_t)blockIdx.x * N * 3;
+    T m[3] = {(T)1e6f, (T)1e6f, (T)1e6f};
+    for (int i = threadIdx.x; i < N; i += blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const T v = cloud[(size_t)i * 3 + a];
+            m[a] = v < m[a] ? v : m[a];
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        m[a] = wave_min(m[a]);
+        if ((threadIdx.x & 63) == 0) red[a][threadIdx.x >> 6] = m[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        T r = red[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) r = red[threadIdx.x][w] < r ? red[threadIdx.x][w] : r;
+        cmin[(size_t)blockIdx.x * 3 + threadIdx.x] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // search: the geometry of the op, done ONCE per (points, filter extents, stride, voxel).
 // One workgroup (4 waves) per query tile, candidate tiles in groups of at most `gtiles`:
 //   P1  pre-filter: waves split the candidate tiles; 64-bit hit masks + per-tile totals -> LDS
@@ -349,12 +379,13 @@ __device__ __forceinline__ uint32_t backward_tap(const T *p, const PointRec<T> &
     return (uint32_t)((tz * st.ext[1] + ty) * st.ext[0] + tx);          // .cpp:677
 }
 
-template <typename T>
+template <typename T, bool WIN>   // WIN: replicate the reference grid's candidate window (even dilated extents only)
 __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes,
                                             const Stencil<T> &st, int N, int ntiles, int gtiles, int ngroups,
                                             const BlockMap &bm, int32_t *__restrict__ count,
                                             PairEntry *__restrict__ pairs, const CacheCtl &cc,
-                                            uint2 *__restrict__ segs, uint2 *__restrict__ qsegs)
+                                            uint2 *__restrict__ segs, uint2 *__restrict__ qsegs,
+                                            const T *__restrict__ cmin)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
@@ -363,6 +394,8 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
     off += align16((size_t)st.ntap * kCntStride * 4);
     CentreRec<T> *centres = reinterpret_cast<CentreRec<T> *>(smem + off);
     off += align16(sizeof(CentreRec<T>) * 64);
+    int32_t *ccell = reinterpret_cast<int32_t *>(smem + off);   // [64][3] grid cells of the centres (window mode)
+    off += 64 * 3 * 4;
     uint64_t *masks = reinterpret_cast<uint64_t *>(smem + off);
     off += align16((size_t)gtiles * 64 * 8);
     uint32_t *tot = reinterpret_cast<uint32_t *>(smem + off);
@@ -392,6 +425,18 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
     make_query(q, cloud_pts[(size_t)qt * kTile + lane], st);
     const bool qvalid = q.orig >= 0;
     load_centres(centres, q);
+    T vmin[3] = {(T)0, (T)0, (T)0};
+    if constexpr (WIN) {
+        Window<T> w;
+        make_window(w, cloud_pts[(size_t)qt * kTile + lane], st, cmin + (size_t)b * 3);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vmin[a] = w.vmin[a];
+        if (wave == 0) {
+            ccell[lane * 3 + 0] = w.cell[0];
+            ccell[lane * 3 + 1] = w.cell[1];
+            ccell[lane * 3 + 2] = w.cell[2];
+        }
+    }
     __syncthreads();
 
     for (int g = 0; g < ngroups; ++g) {
@@ -433,8 +478,13 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
             uint32_t base = 0, ok = 0;
             if (pairs != nullptr) {
                 if (lane == 0) {
+                    // reserve L slots of the cloud's region.  A reservation that does not fit is taken back at once,
+                    // so the 32-bit cursor never holds more than cap (<= 2^31, see carve()) plus the failed requests
+                    // in flight (<= resident workgroups x 2^19 slots < 2^31): it cannot wrap back into the valid
+                    // range however many pre-filter hits a degenerate cloud produces
                     base = L ? atomicAdd(&cc.cursor[b], (uint32_t)L) : 0u;
                     ok = (base <= cap && (uint32_t)L <= cap - base) ? 1u : 0u;
+                    if (!ok) atomicSub(&cc.cursor[b], (uint32_t)L);
                     base += region;
                     segs[((size_t)b * ntiles + qt) * ngroups + g] =
                         ok ? make_uint2(base, (uint32_t)L) : make_uint2(0u, kSegOverflow);
@@ -469,8 +519,9 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
                     const uint32_t ql = (e >> 6) & 63u, c = e & 63u, ct = e >> 12;
                     const CentreRec<T> cr = centres[ql];
                     const PointRec<T> v = cloud_pts[(size_t)ct * kTile + c];
-                    const bool out = (v.x < cr.lo[0]) | (v.x > cr.hi[0]) | (v.y < cr.lo[1]) | (v.y > cr.hi[1]) |
-                                     (v.z < cr.lo[2]) | (v.z > cr.hi[2]);                       // .cpp:277
+                    bool out = (v.x < cr.lo[0]) | (v.x > cr.hi[0]) | (v.y < cr.lo[1]) | (v.y > cr.hi[1]) |
+                               (v.z < cr.lo[2]) | (v.z > cr.hi[2]);                             // .cpp:277
+                    if constexpr (WIN) { if (!out) out = outside_window(v.x, v.y, v.z, vmin, ccell + ql * 3, st); }   // .cpp:260-266
                     uint32_t fwd = kNoTap, bwd = kNoTap;
                     if (!out) {
                         const int tx = axis_tap(v.x, cr.lo[0], st.voxel, st.full[0], tapmap);
@@ -537,15 +588,16 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
         }
 }
 
-template <typename T>
+template <typename T, bool WIN>
 __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restrict__ pts,
                                                      const T *__restrict__ boxes, Stencil<T> st, int N,
                                                      int ntiles, int gtiles, int ngroups, BlockMap bm,
                                                      int32_t *__restrict__ count,
                                                      PairEntry *__restrict__ pairs, CacheCtl cc,
-                                                     uint2 *__restrict__ segs, uint2 *__restrict__ qsegs)
+                                                     uint2 *__restrict__ segs, uint2 *__restrict__ qsegs,
+                                                     const T *__restrict__ cmin)
 {
-    search_tile<T>(pts, boxes, st, N, ntiles, gtiles, ngroups, bm, count, pairs, cc, segs, qsegs);
+    search_tile<T, WIN>(pts, boxes, st, N, ntiles, gtiles, ngroups, bm, count, pairs, cc, segs, qsegs, cmin);
 }
 
 // Several stencils over the same sorted points in ONE launch (blockIdx.y = stencil): the models' layers share
@@ -562,14 +614,14 @@ template <typename T> struct SearchJob {
 template <typename T> struct SearchJobs {
     SearchJob<T> job[kMaxJobs];
 };
-template <typename T>
+template <typename T, bool WIN>
 __global__ __launch_bounds__(256) void search_multi_kernel(const PointRec<T> *__restrict__ pts,
                                                            const T *__restrict__ boxes, int N, int ntiles,
                                                            int gtiles, int ngroups, BlockMap bm,
-                                                           SearchJobs<T> jobs)
+                                                           SearchJobs<T> jobs, const T *__restrict__ cmin)
 {
     const SearchJob<T> &j = jobs.job[blockIdx.y];
-    search_tile<T>(pts, boxes, j.st, N, ntiles, gtiles, ngroups, bm, j.count, j.pairs, j.cc, j.segs, j.qsegs);
+    search_tile<T, WIN>(pts, boxes, j.st, N, ntiles, gtiles, ngroups, bm, j.count, j.pairs, j.cc, j.segs, j.qsegs, cmin);
 }
 
 // ---------------------------------------------------------------------------------
@@ -648,7 +700,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
     int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged,
-    int act)   // act != 0 (small path only): store selu(out), the models' layer (pointcnn2_acsd.py:48-49)
+    int act,   // act != 0 (small path only): store selu(out), the models' layer (pointcnn2_acsd.py:48-49)
+    const T *__restrict__ cmin)   // per-cloud grid origin (window-mode stencils, overflow path only)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -772,10 +825,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const T *cloud_box = boxes + (size_t)b * ntiles * 6;
         Query<T> q;
         make_query(q, me, st);
+        Window<T> win;
+        if (cmin != nullptr) make_window(win, me, st, cmin + (size_t)b * 3);
         for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
                           [&](const PointRec<T> &v, int f) {
             accumulate((uint32_t)v.idx, (uint32_t)f, (uint32_t)lane, (T)1 / (T)cnt[f * kCntStride + lane]);
-        });
+        }, cmin != nullptr ? &win : nullptr);
     }
 
     if constexpr (kSmall) {
@@ -832,8 +887,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
     T *__restrict__ partials, const uint8_t *__restrict__ only_flagged,
     int act, const T *__restrict__ addend,   // act != 0 (small path only): `input` is a SELU output; store
                                              // (dX + addend) * selu'(input), the gradient w.r.t. that SELU's argument
-    int gen_slots)                           // generic path: number of grad_filter partial slots the workgroups
+    int gen_slots,                           // generic path: number of grad_filter partial slots the workgroups
                                              // spread their atomics over (slot = workgroup % gen_slots)
+    const T *__restrict__ cmin)              // per-cloud grid origin (window-mode stencils, overflow path only)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -1039,12 +1095,14 @@ __global__ __launch_bounds__(256) void backward_kernel(
             const T *cloud_box = boxes + (size_t)b * ntiles * 6;
             Query<T> q;
             make_query(q, me, st);
+            Window<T> win;
+            if (cmin != nullptr) make_window(win, me, st, cmin + (size_t)b * 3);
             for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, kSmall ? 0 : wave,
                               kSmall ? 1 : kWavesPerBlock, [&](const PointRec<T> &v, int) {
                 const uint32_t fb = backward_tap(q.p, v, st, tapmap);
                 if (fb != kNoTap && (!kSmall || (int)(fb & (kWavesPerBlock - 1)) == wave))
                     accumulate((uint32_t)v.idx, fb, (uint32_t)lane, (T)0);
-            });
+            }, cmin != nullptr ? &win : nullptr);
         }
     }
 

@@ -101,6 +101,26 @@ def test_hip_matches_oracle(dev, case):
     check_against(ref, run_hip(dev, P, X, W, dY, s), dt, dw_floor=floor)
 
 
+@pytest.mark.parametrize("fzyx,s,dt", [((2, 2, 2), (1, 1, 1), np.float32), ((4, 4, 4), (1, 1, 1), np.float32),
+                                       ((2, 2, 2), (2, 2, 2), np.float32), ((2, 3, 2), (1, 2, 2), np.float64),
+                                       ((4, 2, 3), (1, 1, 1), np.float64), ((2, 2, 2), (1, 1, 1), np.float64)])
+def test_even_extents_on_voxel_aligned_clouds(dev, fzyx, s, dt):
+    """Even dilated extents on voxel-aligned data: the reference's +-n cell window (.cpp:247-266) rejects some
+    candidates that pass the inclusive box test.  Decisions must still be integer-exact -- through the pair lists
+    and through the kernels' own search (pair buffer overflow fallback)."""
+    B, N, ci, co = 2, 600, 3, 9
+    P, X, W, dY = make_case("vlattice", B, N, ci, co, fzyx, seed=1200, dtype=dt)
+    ref = (oracle.neighbor_count(P, fzyx, s, VOX), oracle.forward(P, X, W, s, VOX)) + oracle.backward(dY, P, X, W, s, VOX)
+    check_against(ref, run_hip(dev, P, X, W, dY, s), dt)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    cache = op.NeighborCache(B, N, tdt, dev, slots=1, max_taps=int(np.prod(fzyx)), pairs_per_point=1, max_cin=ci,
+                             max_cout=co)
+    y, dx, dw = _both(dev, cache, P, X, W, dY, s)
+    tol_y, tol_w = TOL[np.dtype(dt)]
+    assert rel_err(y.cpu().numpy(), ref[1]) <= tol_y and rel_err(dx.cpu().numpy(), ref[2]) <= tol_y
+    assert rel_err(dw.cpu().numpy(), ref[3]) <= tol_w
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 127, 129, 200])
 def test_ragged_point_counts(dev, N):
     """Tiles are 64 points: sizes around the tile boundary, including a single point."""
