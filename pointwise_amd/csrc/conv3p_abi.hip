@@ -7,8 +7,8 @@
 //
 // Pipeline of one op call (all on the caller's stream, no host synchronisation):
 //   prep_sort_kernel   hash the clouds; re-sort + re-box only clouds whose content changed
-//   search_kernel      per-tap populations + centre-major pair lists   (skipped per cloud when
-//   finalise_kernel    normalisers of every pair                        the slot is current)
+//   search_kernel      per-tap populations + centre-major pair lists   (skipped per cloud when the slot is
+//                      current; its last workgroup per cloud commits the slot)
 //   forward_kernel / backward_kernel + reduce_partials_kernel          the accumulation (register path), or
 //   deep_order / deep_sched / deep_plan + deep_gemm / deep_dw / deep_reduce   (matrix-core path, conv3p_deep.hpp), or
 //   the generic forms of forward_kernel / backward_kernel (any channel counts, fp64)
@@ -32,9 +32,9 @@ constexpr size_t kAlign = 256;
 inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 // ----------------------------------------------------------------------------- profiling
-enum Kind { K_PREP = 0, K_SEARCH, K_FINALISE, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET,
+enum Kind { K_PREP = 0, K_SEARCH, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET,
             K_DEEP_GEMM, K_DEEP_DW, K_TRANSPOSE, K_DEEP_ORDER, K_NKINDS };
-const char *const kKindName[K_NKINDS] = {"prep_kernel", "search_kernel", "finalise_kernel", "forward_kernel",
+const char *const kKindName[K_NKINDS] = {"prep_kernel", "search_kernel", "forward_kernel",
                                          "backward_kernel", "reduce_partials_kernel", "selu_kernel",
                                          "selu_grad_kernel", "memset", "deep_gemm_kernel", "deep_dw_kernel",
                                          "transpose_filter_kernel", "deep_order_kernel"};
@@ -164,14 +164,14 @@ template <typename T> struct Layout {
     T *cmin;   // [B][3] origin of the reference's uniform grid (stencils with an even dilated extent only)
     // per slot
     struct Slot {
-        uint32_t *built_version, *rebuilt, *cursor;
+        uint32_t *built_version, *cursor, *ticket;
         unsigned long long *built_tag;
-        int32_t *count;
+        int32_t *count, *tcount;   // populations: original-index order (B,N,F) / tile-major [tile][F][64]
         uint2 *segs, *qsegs;
         PairEntry *pairs;
     };
     std::vector<Slot> slot;
-    uint32_t *cursor_all;   // [nslots][B]
+    uint32_t *cursor_all;   // [nslots][2][B]: pair allocator and completion ticket of every slot
     int nclouds;
     uint32_t pairs_per_cloud;
     int gtiles, ngroups;
@@ -210,14 +210,15 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
     L.pairs_per_cloud = (uint32_t)ppc;
     L.slot.resize(nslots);
     L.nclouds = B;
-    L.cursor_all = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * nslots));
+    L.cursor_all = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * nslots * 2));
     for (int s = 0; s < nslots; ++s) {
         auto &S = L.slot[s];
         S.built_version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
-        S.rebuilt = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
-        S.cursor = L.cursor_all ? L.cursor_all + (size_t)s * B : nullptr;
+        S.cursor = L.cursor_all ? L.cursor_all + (size_t)(2 * s) * B : nullptr;
+        S.ticket = L.cursor_all ? L.cursor_all + (size_t)(2 * s + 1) * B : nullptr;
         S.built_tag = reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)B));
         S.count = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)B * N * ntap_max));
+        S.tcount = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)B * ntiles * kTile * ntap_max));
         S.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups));
         S.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups * 64));
         S.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * (size_t)B * ppc));
@@ -313,8 +314,8 @@ template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned l
     cc.version = L.version;
     cc.built_version = L.slot[slot].built_version;
     cc.built_tag = L.slot[slot].built_tag;
-    cc.rebuilt = L.slot[slot].rebuilt;
     cc.cursor = L.slot[slot].cursor;
+    cc.ticket = L.slot[slot].ticket;
     cc.cursor_all = L.cursor_all;
     cc.nslots = (int)L.slot.size();
     cc.nclouds = L.nclouds;
@@ -329,7 +330,7 @@ template <typename T> int run_prep(const T *points, const Call<T> &c)
 {
     if (c.skip_prep) {
         if (c.evicted_hinted)   // prep_sort_kernel would have done this for an un-hinted call
-            return hipMemsetAsync(c.L.slot[c.slot].cursor, 0, sizeof(uint32_t) * (size_t)c.d.B, c.s) == hipSuccess
+            return hipMemsetAsync(c.L.slot[c.slot].cursor, 0, sizeof(uint32_t) * 2 * (size_t)c.d.B, c.s) == hipSuccess
                        ? CONV3P_OK : CONV3P_ERR_LAUNCH;
         return CONV3P_OK;
     }
@@ -366,7 +367,7 @@ template <typename T> int run_cloud_min(const T *points, const Call<T> &c)
     return hip_ok();
 }
 
-// search (+ finalise when pair lists are wanted).  count: where the populations go.
+// search.  count: where the populations go.
 template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
     if (c.skip_search && with_pairs) return CONV3P_OK;
@@ -382,16 +383,10 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes, st, d.N, d.ntiles,
                                c.L.gtiles, c.L.ngroups, bm, count, with_pairs ? S.pairs : nullptr, c.cc, S.segs, S.qsegs,
-                               cmin);
+                               cmin, with_pairs ? S.tcount : nullptr);
         };
         if (st.window) launch(search_kernel<T, true>, c.L.cmin);
         else launch(search_kernel<T, false>, static_cast<const T *>(nullptr));
-    }
-    TRY(hip_ok());
-    if (with_pairs) {
-        Scope sc2(K_FINALISE, c.s);
-        hipLaunchKernelGGL(finalise_kernel<T>, dim3(grid_of(bm)), dim3(256), 0, c.s, c.L.pts, count, d.N, d.ntiles,
-                           c.L.ngroups, st.ntap, bm, S.pairs, S.segs, c.cc);
     }
     return hip_ok();
 }
@@ -404,7 +399,7 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
     const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * ((CI * CO) | 1) * sizeof(T)) : 0) +
-                       a16((size_t)st.ntap * kCntStride * 4) +
+                       a16((size_t)st.ntap * kCntStride * sizeof(T)) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
                        (CI > 0 ? a16((size_t)kWavesPerBlock * CO * 64 * sizeof(T)) : 0);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
@@ -414,7 +409,7 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, d.Cin, d.Cout,
-                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0, st.window ? c.L.cmin : nullptr);
+                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0, st.window ? c.L.cmin : nullptr, S.tcount);
     return hip_ok();
 }
 
@@ -430,7 +425,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     size_t tail = (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)64 * CI * sizeof(T)) : 0) + a16((size_t)kWavesPerBlock * 192 * 4);
     const size_t red = CI > 0 ? a16((size_t)kWavesPerBlock * CI * 64 * sizeof(T)) : 0;
     if (tail < red) tail = red;
-    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) : 0) + 256 + tail;
+    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) + a16(256 * sizeof(T)) : 0) + 256 + tail;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_BACKWARD, c.s);
@@ -468,7 +463,7 @@ inline bool deep_shape(int elem, int cin, int cout)
 constexpr int kDwItems = 1024;        // target number of deep_dw_kernel work items (2 rounds at 2 per CU)
 struct DeepScratch {   // carved from the per-call scratch region
     float *wt;             // filter transposed [F][Cout][Cin]
-    uint32_t *tap_order;   // per pair slot: tile tap-major record order
+    uint2 *tap_meta;       // per pair slot, tap-major inside a tile: {neighbour, centre lane | population << 8}
     uint32_t *tap_off;     // [tiles][F+1]
     uint8_t *tile_flag;    // [tiles]
     uint32_t *sched;       // [8][sched_cap] launch order of the tiles per XCD (deep_sched_kernel)
@@ -488,7 +483,7 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
     s.wt = reinterpret_cast<float *>(take(nw * 4));
-    s.tap_order = reinterpret_cast<uint32_t *>(take(pair_slots * 4));
+    s.tap_meta = reinterpret_cast<uint2 *>(take(pair_slots * 8));
     s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
     s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
@@ -508,11 +503,12 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     const Dims &d = c.d;
     if (d.ntap > 64) return CONV3P_ERR_UNSUPPORTED;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = (size_t)18 * d.ntap * 4;
+    const size_t lds = (size_t)18 * d.ntap * 4 + 256;
     Scope sc(K_DEEP_ORDER, c.s);
     if (BWD) TRY(zero_async(ds.tap_total, 65 * 4, c.s));
-    hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, S.pairs, S.segs,
-                       d.ntap, ds.tap_order, ds.tap_off, ds.tile_flag, BWD ? ds.tap_total : nullptr);
+    hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, c.L.pts, S.count,
+                       S.pairs, S.segs, d.N, d.ntiles, d.ntap, ds.tap_meta, ds.tap_off, ds.tile_flag,
+                       BWD ? ds.tap_total : nullptr);
     hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, S.segs, d.B, d.ntiles, ds.sched_cap, ds.sched);
     if (BWD)
         hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.tap_off, d.ntap, d.B * d.ntiles, kDwItems,
@@ -533,7 +529,7 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_gemm_kernel<KD, ND, BWD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((deep_gemm_kernel<KD, ND, BWD>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs,
-                       S.segs, src, Bm, d.N, d.ntiles, d.ntap, ds.sched, ds.sched_cap, out, ds.tap_order, ds.tap_off,
+                       S.segs, src, Bm, d.N, d.ntiles, d.ntap, ds.sched, ds.sched_cap, out, ds.tap_meta, ds.tap_off,
                        ds.tile_flag);
     return hip_ok();
 }
@@ -573,7 +569,7 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_dw_kernel<CI, CO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(kDwItems + 64), dim3(256), lds, c.s, c.L.pts, S.pairs, S.segs,
-                           ds.tap_order, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap, ds.tile_flag, ds.items,
+                           ds.tap_meta, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap, ds.tile_flag, ds.items,
                            ds.tap_total + 64, ds.partials);
     }
     TRY(hip_ok());
@@ -739,7 +735,7 @@ int prepare_impl(const T *points, const int32_t *stride, T voxel, int B, int N, 
 }
 
 // geometry of K stencils (same filter extents, K strides) over the same points: one prep, ONE search launch and
-// ONE finalise launch for all of them
+// nothing else
 template <typename T>
 int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, int B, int N, int fz, int fy,
                        int fx, Where wh, void *stream)
@@ -772,6 +768,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         j.st = st;
         j.cc = c.cc;
         j.count = S.count;
+        j.tcount = S.tcount;
         j.pairs = S.pairs;
         j.segs = S.segs;
         j.qsegs = S.qsegs;
@@ -787,12 +784,6 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         };
         if (any_window) launch(search_multi_kernel<T, true>);    // window replication is a no-op for odd extents
         else launch(search_multi_kernel<T, false>);
-    }
-    TRY(hip_ok());
-    {
-        Scope sc2(K_FINALISE, s);
-        hipLaunchKernelGGL(finalise_multi_kernel<T>, dim3(grid_of(bm), njobs), dim3(256), 0, s, c.L.pts, c.d.N,
-                           c.d.ntiles, c.L.ngroups, bm, jobs);
     }
     return hip_ok();
 }

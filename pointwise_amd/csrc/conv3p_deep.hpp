@@ -42,14 +42,19 @@ constexpr int kDeepBatch = 256;   // records whose metadata is fetched at once
 // deep_order_kernel: tap-major order of every query tile's records (stable counting sort by tap: taps ascending,
 // inside a tap the search's record order -> deterministic).  One workgroup per tile.
 //   tap_off[tile][f] .. tap_off[tile][f+1] : slots of tap f (relative to the tile's segment)
-//   tap_order[segment start + slot]        : record index relative to the tile's segment
-// BWD: taps = backward taps, records with rcp_bwd == 0 dropped; else forward taps, false positives dropped.
+//   tap_meta[segment start + slot]         : {neighbour's original index, centre lane | population << 8} of the
+//                                            record in that slot -- everything the GEMM kernels need of a record, so
+//                                            they fetch it with ONE load (no order -> record -> population chain)
+// BWD: taps = backward taps, population = that of the neighbour's tap (one 4-byte gather); holes and records whose
+// population is 0 (.cpp:679) dropped.  Else forward taps, population of the centre's tap; false positives dropped.
 // Tiles whose pair reservation overflowed get an empty order and tile_flag = 1 (the generic kernel takes them).
 // ---------------------------------------------------------------------------------------------
 template <bool BWD>
-__global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__restrict__ pairs,
-                                                         const uint2 *__restrict__ segs, int ntap,
-                                                         uint32_t *__restrict__ tap_order,
+__global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *__restrict__ pts,
+                                                         const int32_t *__restrict__ count,
+                                                         const PairEntry *__restrict__ pairs,
+                                                         const uint2 *__restrict__ segs, int N, int ntiles, int ntap,
+                                                         uint2 *__restrict__ tap_meta,
                                                          uint32_t *__restrict__ tap_off,
                                                          uint8_t *__restrict__ tile_flag,
                                                          uint32_t *__restrict__ tap_total)   // [ntap] += (may be null)
@@ -58,7 +63,10 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__rest
     uint32_t *tot = reinterpret_cast<uint32_t *>(smem);            // [ntap]     records per tap (whole tile)
     uint32_t *base = tot + ntap;                                    // [ntap]     next free slot of each tap
     uint32_t *wcnt = base + ntap;                                   // [16][ntap] per wave-chunk counts of a super-chunk
+    int32_t *qorig = reinterpret_cast<int32_t *>(wcnt + 16 * ntap); // [64] original indices of the tile's centres
     const size_t tile = blockIdx.x;
+    const int32_t *cnt_cloud = count + (tile / (size_t)ntiles) * (size_t)N * ntap;
+    if (threadIdx.x < 64) qorig[threadIdx.x] = pts[tile * kTile + threadIdx.x].idx;
     const uint2 tseg = segs[tile];                                  // ngroups == 1 on this path (host checks)
     uint32_t *toff = tap_off + tile * (size_t)(ntap + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -70,14 +78,24 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__rest
     if (tid == 0) tile_flag[tile] = 0;
     const PairEntry *seg = pairs + tseg.x;
     const uint32_t n = tseg.y;
-    auto key_of = [&](const PairEntry &en) -> uint32_t {
-        const bool ok = BWD ? (en.rcp_bwd > 0.0f) : (code_fwd(en.code) != kNoTap);
-        return ok ? (BWD ? code_bwd(en.code) : code_fwd(en.code)) : 0xFFFFFFFFu;
+    // tap of a record (0xFFFFFFFF = dropped) and the population its contribution is divided by
+    auto key_of = [&](const PairEntry &en, uint32_t &pop) -> uint32_t {
+        const uint32_t fw = code_fwd(en.code), bw = code_bwd(en.code);
+        pop = 0;
+        if (fw == kNoTap) return 0xFFFFFFFFu;
+        if (BWD) {
+            if (bw == kNoTap) return 0xFFFFFFFFu;
+            pop = (uint32_t)cnt_cloud[(size_t)en.cand * ntap + bw];
+            return pop ? bw : 0xFFFFFFFFu;                          // .cpp:679
+        }
+        pop = (uint32_t)cnt_cloud[(size_t)qorig[code_q(en.code)] * ntap + fw];
+        return fw;
     };
     for (uint32_t f = tid; f < (uint32_t)ntap; f += 256) tot[f] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) {                       // totals: order-independent, LDS atomics
-        const uint32_t k = key_of(seg[i]);
+        uint32_t pop;
+        const uint32_t k = key_of(seg[i], pop);
         if (k != 0xFFFFFFFFu) atomicAdd(&tot[k], 1u);
     }
     __syncthreads();
@@ -93,13 +111,21 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__rest
     }
     __syncthreads();
     // stable ranks, 1024 records (4 per thread, 16 wave-chunks of 64 consecutive records) per round
-    uint32_t *ord = tap_order + tseg.x;
+    uint2 *meta = tap_meta + tseg.x;
     for (uint32_t s0 = 0; s0 < n; s0 += 1024) {
         uint32_t key[4], rank[4];
+        uint2 rec[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = s0 + (uint32_t)u * 256u + tid;
-            key[u] = i < n ? key_of(seg[i]) : 0xFFFFFFFFu;
+            key[u] = 0xFFFFFFFFu;
+            rec[u] = make_uint2(0u, 0u);
+            if (i < n) {
+                const PairEntry en = seg[i];
+                uint32_t pop;
+                key[u] = key_of(en, pop);
+                rec[u] = make_uint2(en.cand, code_q(en.code) | (pop << 8));
+            }
             rank[u] = 0;
         }
         for (int f = 0; f < ntap; ++f) {
@@ -126,7 +152,7 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PairEntry *__rest
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (key[u] != 0xFFFFFFFFu)
-                ord[wcnt[((uint32_t)u * 4u + wave) * (uint32_t)ntap + key[u]] + rank[u]] = s0 + (uint32_t)u * 256u + tid;
+                meta[wcnt[((uint32_t)u * 4u + wave) * (uint32_t)ntap + key[u]] + rank[u]] = rec[u];
         __syncthreads();
     }
 }
@@ -180,23 +206,22 @@ __global__ __launch_bounds__(1024) void deep_sched_kernel(const uint2 *__restric
     for (int i = threadIdx.x; i < cap; i += blockDim.x) out[i] = i < n ? (uint32_t)keys[i] : 0xFFFFFFFFu;
 }
 
-// metadata of up to kDeepBatch records of one (tile, tap) run -> LDS (thread = record: two dependent loads).
+// metadata of up to kDeepBatch records of one (tile, tap) run -> LDS (thread = record: one coalesced load).
 // mqr[t] = {centre lane, bits of 1/count}; entries past the run: row 0 (never loaded), centre 64 (matches no
 // lane; row 64 of deep_dw_kernel's X tile is all zero), weight 0.
-template <bool BWD>
-__device__ __forceinline__ void deep_fetch_meta(const PairEntry *__restrict__ seg, const uint32_t *__restrict__ ord,
-                                                uint32_t e0, uint32_t e1, uint32_t *mcand, uint2 *mqr)
+__device__ __forceinline__ void deep_fetch_meta(const uint2 *__restrict__ meta, uint32_t e0, uint32_t e1,
+                                                uint32_t *mcand, uint2 *mqr)
 {
     const uint32_t t = threadIdx.x;
     uint32_t cand = 0, q = 64;
     float rcp = 0.0f;
     if (e0 + t < e1) {
-        PairEntry en;
-        if (CONV3P_ABLATE & 4194304) { en.cand = (e0 + t) & 1023u; en.code = pair_code(0, 0, t & 63u); en.rcp_fwd = en.rcp_bwd = 1.0f; }
-        else en = seg[ord[e0 + t]];
-        cand = en.cand;
-        q = code_q(en.code);
-        rcp = BWD ? en.rcp_bwd : en.rcp_fwd;
+        uint2 m;
+        if (CONV3P_ABLATE & 4194304) m = make_uint2((e0 + t) & 1023u, (t & 63u) | (1u << 8));
+        else m = meta[e0 + t];
+        cand = m.x;
+        q = m.y & 0xFFu;
+        rcp = 1.0f / (float)(m.y >> 8);       // the IEEE quotient, as the register path computes it
     }
     mcand[t] = cand;
     mqr[t] = make_uint2(q, __builtin_bit_cast(uint32_t, rcp));
@@ -221,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                                                         const float *__restrict__ Bm, int N, int ntiles, int ntap,
                                                         const uint32_t *__restrict__ sched, int sched_cap,
                                                         float *__restrict__ out,
-                                                        const uint32_t *__restrict__ tap_order,
+                                                        const uint2 *__restrict__ tap_meta,
                                                         const uint32_t *__restrict__ tap_off,
                                                         uint8_t *__restrict__ tile_flag)
 {
@@ -271,8 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
         }
         return;
     }
-    const PairEntry *seg = pairs + tseg.x;
-    const uint32_t *ord = tap_order + tseg.x;
+    const uint2 *meta = tap_meta + tseg.x;
     const uint32_t *toff = tap_off + tile_id * (size_t)(ntap + 1);
     const float *src_cloud = src + (size_t)b * N * KDIM;
 
@@ -326,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             for (int r = 0; r < 16; ++r) am[j][r] = 0.0f;
         for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
             __syncthreads();                                 // meta / LDS union free
-            deep_fetch_meta<BWD>(seg, ord, eb, e1, mcand, mqr);
+            deep_fetch_meta(meta, eb, e1, mcand, mqr);
             __syncthreads();
             GDBG(0)
             const uint32_t nrec = min((uint32_t)kDeepBatch, e1 - eb);
@@ -612,7 +636,7 @@ __global__ __launch_bounds__(256) void deep_reduce_kernel(const float *__restric
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void deep_dw_kernel(
     const PointRec<float> *__restrict__ pts, const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs,
-    const uint32_t *__restrict__ tap_order, const uint32_t *__restrict__ tap_off, const float *__restrict__ grad_out,
+    const uint2 *__restrict__ tap_meta, const uint32_t *__restrict__ tap_off, const float *__restrict__ grad_out,
     const float *__restrict__ input, int B, int N, int ntiles, int ntap, const uint8_t *__restrict__ tile_flag,
     const uint4 *__restrict__ items, const uint32_t *__restrict__ nitems, float *__restrict__ partials)
 {
@@ -664,13 +688,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         if (e0 == e1 || tile_flag[tile]) continue;          // uniform: nothing with this tap / generic kernel's tile
         const int b = (int)(tile / ntiles);
         const uint2 tseg = segs[tile];
-        const PairEntry *seg = pairs + tseg.x;
-        const uint32_t *ord = tap_order + tseg.x;
+        const uint2 *meta = tap_meta + tseg.x;
         const float *dy_cloud = grad_out + (size_t)b * N * COUT;
         DBG_T(0)
         __syncthreads();                                    // previous tile's X / rows consumed
         if (wave == 0) qorig[lane] = pts[tile * kTile + lane].idx;
-        deep_fetch_meta<true>(seg, ord, e0, e1, mcand, mqr);
+        deep_fetch_meta(meta, e0, e1, mcand, mqr);
         __syncthreads();
         DBG_T(1)
         // X tile (rows by original index; padding centres -> 0): all of a thread's float4 loads in flight together
@@ -715,7 +738,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
             if (eb != e0) {
                 __syncthreads();
-                deep_fetch_meta<true>(seg, ord, eb, e1, mcand, mqr);
+                deep_fetch_meta(meta, eb, e1, mcand, mqr);
                 __syncthreads();
             }
             const uint32_t nrec = min((uint32_t)kDeepBatch, e1 - eb);

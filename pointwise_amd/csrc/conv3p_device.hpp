@@ -159,11 +159,6 @@ __device__ __forceinline__ double lane_xor32(double v)
     const unsigned long long r = (unsigned long long)lane_xor32((uint32_t)b) | ((unsigned long long)lane_xor32((uint32_t)(b >> 32)) << 32);
     return __builtin_bit_cast(double, r);
 }
-// 1/count in T from the pair record's fp32 1/count: exact for fp32; for fp64 the count (an integer < 2^23) is
-// recovered exactly and the reciprocal taken in double (the reference divides by the count in T, .cpp:492, :692)
-__device__ __forceinline__ float rcp_in(float r, float) { return r; }
-__device__ __forceinline__ double rcp_in(float r, double) { return 1.0 / (double)__builtin_rintf(1.0f / r); }
-
 template <typename T> struct Limits;
 template <> struct Limits<float> {
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
@@ -473,24 +468,23 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
 
 
 // ---------------------------------------------------------------------------------------------
-// Pair lists.  The search kernel resolves every (centre j, neighbour ii) pair once and stores
+// Pair lists.  The search kernel resolves every (centre j, neighbour ii) pair once and stores the 8-byte
 //   PairEntry{ cand = original index of ii,  code = fwd_tap | bwd_tap << 12 | q << 24 }
 // fwd_tap : tap of ii inside j's box                      (forward,  .cpp:280-290)
 // bwd_tap : tap of j inside ii's box, kNoTap for a hole   (backward, .cpp:662-677)
 // q       : lane (0..63) of the centre inside its query tile
 // All pairs of a query tile are contiguous (one segment per tile), centre-major inside.  Entries
 // whose exact test failed (pre-filter false positives) carry fwd_tap = kNoTap and are skipped by
-// the consumers.  finalise_kernel adds the two normalisers once the populations of ALL points
-// are known: rcp_fwd = 1/count[j][fwd], rcp_bwd = 1/count[ii][bwd] (0 for a hole or an empty
-// tap, the reference's `count == 0` skip, .cpp:679).
+// the consumers.  The normalisers are NOT stored: the forward's 1/count[j][fwd] comes from the tile's own
+// population rows (an LDS table of reciprocals per workgroup), the backward's 1/count[ii][bwd] from one
+// 4-byte gather of the neighbour's population next to its grad_out row (0 = empty tap, the reference's
+// `count == 0` skip, .cpp:679).  No pass over the lists is needed once the populations are complete.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kNoTap = 0xFFFu;
 constexpr uint32_t kSegOverflow = 0xFFFFFFFFu;
-struct __attribute__((aligned(16))) PairEntry {
+struct __attribute__((aligned(8))) PairEntry {
     uint32_t cand;
     uint32_t code;
-    float rcp_fwd;   // 1 / population of tap fwd of the centre   (finalise_kernel; fp32 ops only)
-    float rcp_bwd;   // 1 / population of tap bwd of the neighbour, 0 when the pair contributes nothing
 };
 __device__ __forceinline__ uint32_t pair_code(uint32_t fwd, uint32_t bwd, uint32_t q) { return fwd | (bwd << 12) | (q << 24); }
 __device__ __forceinline__ uint32_t code_fwd(uint32_t c) { return c & 0xFFFu; }

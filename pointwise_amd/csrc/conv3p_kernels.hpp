@@ -24,8 +24,9 @@ namespace conv3p {
 //               workgroup per cloud)
 // and per search slot (one slot = one stencil: filter extents, stride, voxel)
 //   built_version[b], built_tag[b]   what the slot's pair lists of cloud b were built from
-//   rebuilt[b]                       == epoch of the call that rebuilt them (search -> finalise)
 //   cursor[b]                        pair-slot allocator of cloud b's region
+//   ticket[b]                        query tiles of cloud b that have finished rebuilding in the running search
+//                                    launch; the last one commits built_version / built_tag and resets it to 0
 // A slot is valid for cloud b iff built_version[b] == version[b] && built_tag[b] == tag.
 // Nothing is ever read back by the host: every decision is taken on the device, so a stale
 // or recycled buffer can only cost a rebuild, never a wrong result.
@@ -36,9 +37,9 @@ struct CacheCtl {
     uint32_t *version;               // [B]
     uint32_t *built_version;         // [B] of the slot in use
     unsigned long long *built_tag;   // [B]
-    uint32_t *rebuilt;               // [B]
     uint32_t *cursor;                // [B] of the slot in use
-    uint32_t *cursor_all;            // [nslots][B]: all slots' allocators (contiguous)
+    uint32_t *ticket;                // [B] of the slot in use
+    uint32_t *cursor_all;            // [nslots][2][B]: all slots' allocators and tickets (contiguous)
     int nslots, nclouds;
     unsigned long long tag;
     uint32_t epoch;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const T *__restrict__ points,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cc.version[blockIdx.y] += 1;
         cc.hash[blockIdx.y] = 0;
-        for (int sl = 0; sl < cc.nslots; ++sl) cc.cursor_all[(size_t)sl * cc.nclouds + blockIdx.y] = 0;
+        for (int sl = 0; sl < 2 * cc.nslots; ++sl) cc.cursor_all[(size_t)sl * cc.nclouds + blockIdx.y] = 0;
     }
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -196,11 +197,14 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
                 cc.hash[b] = t;
                 cc.version[b] += 1;
                 // every slot's lists of this cloud are stale now: their allocators restart from empty
-                for (int sl = 0; sl < cc.nslots; ++sl) cc.cursor_all[(size_t)sl * cc.nclouds + b] = 0;
+                for (int sl = 0; sl < 2 * cc.nslots; ++sl) cc.cursor_all[(size_t)sl * cc.nclouds + b] = 0;
             }
             // the slot about to be used must allocate from an empty region if it is going to rebuild
             const bool valid = same && cc.built_version[b] == cc.version[b] && cc.built_tag[b] == cc.tag;
-            if (!valid) cc.cursor[b] = 0;
+            if (!valid) {
+                cc.cursor[b] = 0;
+                cc.ticket[b] = 0;   // (a never-initialised buffer may hold anything here)
+            }
             hred[16] = same ? 1ull : 0ull;
         }
         __syncthreads();
@@ -385,7 +389,7 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
                                             const BlockMap &bm, int32_t *__restrict__ count,
                                             PairEntry *__restrict__ pairs, const CacheCtl &cc,
                                             uint2 *__restrict__ segs, uint2 *__restrict__ qsegs,
-                                            const T *__restrict__ cmin)
+                                            const T *__restrict__ cmin, int32_t *__restrict__ tcount)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
@@ -411,10 +415,7 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
 
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;   // uniform for the workgroup
-    if (pairs != nullptr) {
-        if (slot_valid(cc, b)) return;        // this cloud's lists are current (uniform)
-        if (threadIdx.x == 0) cc.rebuilt[b] = cc.epoch;
-    }
+    if (pairs != nullptr && slot_valid(cc, b)) return;   // this cloud's lists are current (uniform)
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
     const uint32_t cap = cc.pairs_per_cloud;
@@ -537,8 +538,6 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
                         PairEntry pe;
                         pe.cand = (uint32_t)v.idx;
                         pe.code = pair_code(fwd, bwd, ql);
-                        pe.rcp_fwd = 0.0f;
-                        pe.rcp_bwd = 0.0f;
                         pairs[(size_t)gbase + stream[128 + lane]] = pe;
                     }
                 }
@@ -586,6 +585,26 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
             int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
             for (int f = lane; f < st.ntap; f += 64) row[f] = (int32_t)cnt[f * kCntStride + qq];
         }
+    // the same populations tile-major, [tile][tap][centre lane]: what the forward kernel of this tile turns into its
+    // table of reciprocals with one coalesced read (no dependence on the centres' original indices)
+    if (tcount != nullptr) {
+        int32_t *tc = tcount + ((size_t)b * ntiles + qt) * st.ntap * kTile;
+        for (int e = threadIdx.x; e < st.ntap * kTile; e += blockDim.x) tc[e] = (int32_t)cnt[(e >> 6) * kCntStride + (e & 63)];
+    }
+    // commit: the last query tile of the cloud to finish marks the slot's lists as built from the current
+    // content.  Every workgroup of the cloud passed the validity check before the ticket can reach its final
+    // value, and the marks are only read by later launches, so no fence is needed.
+    if (pairs != nullptr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t t = atomicAdd(&cc.ticket[b], 1u);
+            if (t + 1u == (uint32_t)bm.blocks_per_cloud) {
+                cc.built_version[b] = cc.version[b];
+                cc.built_tag[b] = cc.tag;
+                cc.ticket[b] = 0;
+            }
+        }
+    }
 }
 
 template <typename T, bool WIN>
@@ -595,9 +614,9 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                                                      int32_t *__restrict__ count,
                                                      PairEntry *__restrict__ pairs, CacheCtl cc,
                                                      uint2 *__restrict__ segs, uint2 *__restrict__ qsegs,
-                                                     const T *__restrict__ cmin)
+                                                     const T *__restrict__ cmin, int32_t *__restrict__ tcount)
 {
-    search_tile<T, WIN>(pts, boxes, st, N, ntiles, gtiles, ngroups, bm, count, pairs, cc, segs, qsegs, cmin);
+    search_tile<T, WIN>(pts, boxes, st, N, ntiles, gtiles, ngroups, bm, count, pairs, cc, segs, qsegs, cmin, tcount);
 }
 
 // Several stencils over the same sorted points in ONE launch (blockIdx.y = stencil): the models' layers share
@@ -607,7 +626,7 @@ constexpr int kMaxJobs = 8;
 template <typename T> struct SearchJob {
     Stencil<T> st;
     CacheCtl cc;
-    int32_t *count;
+    int32_t *count, *tcount;
     PairEntry *pairs;
     uint2 *segs, *qsegs;
 };
@@ -621,64 +640,7 @@ __global__ __launch_bounds__(256) void search_multi_kernel(const PointRec<T> *__
                                                            SearchJobs<T> jobs, const T *__restrict__ cmin)
 {
     const SearchJob<T> &j = jobs.job[blockIdx.y];
-    search_tile<T, WIN>(pts, boxes, j.st, N, ntiles, gtiles, ngroups, bm, j.count, j.pairs, j.cc, j.segs, j.qsegs, cmin);
-}
-
-// ---------------------------------------------------------------------------------
-// finalise: once every population is known, store the two normalisers of each pair
-// (dense, thread = pair).  rcp = 1 / (float)count is the correctly rounded IEEE quotient.
-// ---------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void finalise_tile(const PointRec<T> *__restrict__ pts,
-                                              const int32_t *__restrict__ count, int N, int ntiles,
-                                              int ngroups, int ntap, const BlockMap &bm,
-                                              PairEntry *__restrict__ pairs,
-                                              const uint2 *__restrict__ segs, const CacheCtl &cc)
-{
-    __shared__ int32_t qorig[64];
-    int b, qt;
-    if (!block_to_cloud(bm, b, qt)) return;
-    if (cc.rebuilt[b] != cc.epoch) return;   // search_kernel did not rebuild this cloud in this call
-    if (threadIdx.x == 0) {                  // commit (every workgroup of the cloud writes the same values)
-        cc.built_version[b] = cc.version[b];
-        cc.built_tag[b] = cc.tag;
-    }
-    if (threadIdx.x < 64) qorig[threadIdx.x] = pts[((size_t)b * ntiles + qt) * kTile + threadIdx.x].idx;
-    __syncthreads();
-    const int32_t *cnt_cloud = count + (size_t)b * N * ntap;
-    for (int g = 0; g < ngroups; ++g) {
-        const uint2 sg = segs[((size_t)b * ntiles + qt) * ngroups + g];
-        if (sg.y == kSegOverflow) continue;
-        PairEntry *pe = pairs + sg.x;
-        for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
-            PairEntry en = pe[e];                                                    // one 16-byte load
-            const uint32_t fwd = code_fwd(en.code), bwd = code_bwd(en.code);
-            if (fwd == kNoTap) continue;
-            const int cf = cnt_cloud[(size_t)qorig[code_q(en.code)] * ntap + fwd];
-            const int cb = bwd != kNoTap ? cnt_cloud[(size_t)en.cand * ntap + bwd] : 0;
-            en.rcp_fwd = 1.0f / (float)cf;
-            en.rcp_bwd = cb != 0 ? 1.0f / (float)cb : 0.0f;                          // .cpp:678-679
-            pe[e] = en;                                                              // one 16-byte store
-        }
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void finalise_kernel(const PointRec<T> *__restrict__ pts,
-                                                       const int32_t *__restrict__ count, int N, int ntiles,
-                                                       int ngroups, int ntap, BlockMap bm,
-                                                       PairEntry *__restrict__ pairs,
-                                                       const uint2 *__restrict__ segs, CacheCtl cc)
-{
-    finalise_tile<T>(pts, count, N, ntiles, ngroups, ntap, bm, pairs, segs, cc);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void finalise_multi_kernel(const PointRec<T> *__restrict__ pts, int N,
-                                                             int ntiles, int ngroups, BlockMap bm,
-                                                             SearchJobs<T> jobs)
-{
-    const SearchJob<T> &j = jobs.job[blockIdx.y];
-    finalise_tile<T>(pts, j.count, N, ntiles, ngroups, j.st.ntap, bm, j.pairs, j.segs, j.cc);
+    search_tile<T, WIN>(pts, boxes, j.st, N, ntiles, gtiles, ngroups, bm, j.count, j.pairs, j.cc, j.segs, j.qsegs, cmin, j.tcount);
 }
 
 // ---------------------------------------------------------------------------------
@@ -701,7 +663,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
     int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged,
     int act,   // act != 0 (small path only): store selu(out), the models' layer (pointcnn2_acsd.py:48-49)
-    const T *__restrict__ cmin)   // per-cloud grid origin (window-mode stencils, overflow path only)
+    const T *__restrict__ cmin,   // per-cloud grid origin (window-mode stencils, overflow path only)
+    const int32_t *__restrict__ tcount)   // populations tile-major [tile][tap][centre lane] (search_tile)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -715,8 +678,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     // banks (36 x 13 = 468 = 20 mod 32 would put every tap on one of 8 banks: the 36 -> 13 layer ran 2x slower)
     constexpr int WSTR = kSmall ? ((CIN * COUT) | 1) : 1;
     if (kSmall) off += align16((size_t)st.ntap * WSTR * sizeof(T));
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
-    off += align16((size_t)st.ntap * kCntStride * 4);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);   // populations of the tile's centres [tap][65] ...
+    T *rcpt = reinterpret_cast<T *>(smem + off);                // ... or (dense small path) their reciprocals 1/(T)count
+    off += align16((size_t)st.ntap * kCntStride * sizeof(T));
     int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
     off += 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -725,7 +689,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     T *red = reinterpret_cast<T *>(smem + off);   // [4][COUT][64], overflow path only
     const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense path: centre and sub-lane of this thread
 
+    int b, qt;
+    if (!block_to_cloud(bm, b, qt)) return;   // uniform
+    if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
+    // the tile's populations (tile-major copy): issued before the filter so that both are in flight together
+    constexpr int kTcPer = 8;   // 27 taps x 64 centres = 1728 values: 7 per thread
+    int32_t tcv[kTcPer];
+    const bool tc_fits = kSmall && st.ntap * kTile <= kTcPer * 256;
+    if (tc_fits) {
+        const int32_t *tc = tcount + ((size_t)b * ntiles + qt) * st.ntap * kTile;
+#pragma unroll
+        for (int u = 0; u < kTcPer; ++u) {
+            const int e = (int)threadIdx.x + 256 * u;
+            tcv[u] = e < st.ntap * kTile ? tc[e] : 1;
+        }
+    }
     if (kSmall) {
         // filter -> LDS, 8 independent loads per thread in flight (one memory latency per batch, not per element)
         for (uint32_t e0 = threadIdx.x; e0 < (uint32_t)nw; e0 += 8 * 256) {
@@ -740,9 +719,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 }
         }
     }
-    int b, qt;
-    if (!block_to_cloud(bm, b, qt)) return;   // uniform
-    if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
     const PointRec<T> me = cloud_pts[(size_t)qt * kTile + lane];
     if (wave == 0) qorig[lane] = me.idx;
@@ -750,13 +726,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     bool overflow = false;
     for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
     __syncthreads();
-    if (!kSmall || overflow) {
-        // own populations -> LDS [tap][centre] (the dense small path carries 1/count in the pair records)
-        for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
-            const int orig = qorig[qq];
-            if (orig < 0) continue;
-            const int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
-            for (int f = lane; f < st.ntap; f += 64) cnt[f * kCntStride + qq] = (uint32_t)row[f];
+    {
+        // own populations -> LDS [tap][centre]; the dense small path keeps 1 / (T)count instead (the IEEE quotient,
+        // .cpp:483: one division per (centre, tap) here rather than one per pair)
+        const bool as_rcp = kSmall && !overflow;
+        if (as_rcp && tc_fits) {
+#pragma unroll
+            for (int u = 0; u < kTcPer; ++u) {
+                const int e = (int)threadIdx.x + 256 * u;
+                if (e < st.ntap * kTile) rcpt[(e >> 6) * kCntStride + (e & 63)] = (T)1 / (T)tcv[u];
+            }
+        } else {
+            for (int qq = wave; qq < kTile; qq += kWavesPerBlock) {
+                const int orig = qorig[qq];
+                if (orig < 0) continue;
+                const int32_t *row = count + ((size_t)b * N + orig) * st.ntap;
+                for (int f = lane; f < st.ntap; f += 64) {
+                    const int32_t cv = row[f];
+                    if (as_rcp) rcpt[f * kCntStride + qq] = (T)1 / (T)cv;
+                    else cnt[f * kCntStride + qq] = (uint32_t)cv;
+                }
+            }
         }
         __syncthreads();
     }
@@ -806,7 +796,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                     const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
                     if (i < sg.y) {
                         const uint32_t f = code_fwd(cur.code);
-                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)cq, rcp_in(cur.rcp_fwd, (T)0));
+                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)cq, rcpt[f * kCntStride + cq]);
                     }
                     cur = nxt;
                 }
@@ -903,6 +893,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
     if (kSmall) off += align16((size_t)nrows * kCntStride * sizeof(T));
     int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
     off += 256;
+    T *rinv = reinterpret_cast<T *>(smem + off);      // rinv[n] = 1 / (T)n for n < 256 (the IEEE quotient): one LDS read
+    if (kSmall) off += align16(256 * sizeof(T));      //   per pair instead of a division; larger populations divide
     T *red = reinterpret_cast<T *>(smem + off);       // [4][CIN][64]: ALIASES wt | xt | soa (used after them)
     T *wt = reinterpret_cast<T *>(smem + off);        // Wt[row][k], row = f*COUT + c
     if (kSmall) off += align16(nw * sizeof(T));
@@ -930,6 +922,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 }
             }
         }
+        rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;   // [0] = inf, never read (populations of 0 are skipped)
         // G = 0, 16 bytes per store (G is 16-byte aligned, its length is padded to 4 by the LDS carve-up)
         {
             float4 *G4 = reinterpret_cast<float4 *>(G);
@@ -1008,22 +1001,37 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     // lower sub-lane goes first (fixed order), the other retries -> race-free, reproducible.
                     const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                     const PairEntry *pe = pairs + sg.x;
-                    // software pipeline: record two steps ahead, dY row one step ahead
-                    auto live_rec = [&](const PairEntry &r, uint32_t i) { return i < sg.y && r.rcp_bwd > 0.0f; };
+                    // software pipeline: record two steps ahead; dY row and the neighbour's population of the
+                    // backward tap (4-byte gather next to the row) one step ahead
+                    auto live_rec = [&](const PairEntry &r, uint32_t i) {
+                        return i < sg.y && code_fwd(r.code) != kNoTap && code_bwd(r.code) != kNoTap;
+                    };
+                    auto cnt_of = [&](const PairEntry &r, bool live) {
+                        if (CONV3P_ABLATE & 2048) return live ? 1 : 0;   // developer: timing without the gather
+                        return live ? cnt_cloud[(size_t)r.cand * st.ntap + code_bwd(r.code)] : 0;
+                    };
+                    // (with 78 KB of LDS only two workgroups fit a CU, so the latency of the two gathers is hidden by
+                    // depth, not by occupancy: records run three steps ahead, rows and populations two)
                     PairEntry cur = pe[(uint32_t)sub < sg.y ? sub : 0];
                     PairEntry nxt = pe[(uint32_t)sub + 4 < sg.y ? sub + 4 : 0];
-                    T val[COUT];
-                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(live_rec(cur, sub) ? cur.cand : 0) * COUT, val);
+                    PairEntry nx2 = pe[(uint32_t)sub + 8 < sg.y ? sub + 8 : 0];
+                    T val[COUT], nval[COUT];
+                    bool cur_live = live_rec(cur, sub), nxt_live = live_rec(nxt, sub + 4);
+                    int cur_cnt = cnt_of(cur, cur_live), nxt_cnt = cnt_of(nxt, nxt_live);
+                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(cur_live ? cur.cand : 0) * COUT, val);
+                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(nxt_live ? nxt.cand : 0) * COUT, nval);
                     T ablate_sink = (T)0;
                     for (uint32_t i = sub; __any(i < sg.y); i += 4) {
-                        const PairEntry nn = pe[i + 8 < sg.y ? i + 8 : 0];
-                        T nval[COUT];
-                        RowLoader<T, COUT>::load(dy_cloud + (size_t)(live_rec(nxt, i + 4) ? nxt.cand : 0) * COUT, nval);
-                        // rcp_bwd == 0: false positive, hole, or empty tap -> contributes nothing
-                        bool pending = live_rec(cur, i);
+                        const PairEntry nx3 = pe[i + 12 < sg.y ? i + 12 : 0];
+                        T n2val[COUT];
+                        const bool nx2_live = live_rec(nx2, i + 8);
+                        const int nx2_cnt = cnt_of(nx2, nx2_live);
+                        RowLoader<T, COUT>::load(dy_cloud + (size_t)(nx2_live ? nx2.cand : 0) * COUT, n2val);
+                        // false positive, hole, or empty tap (.cpp:679) -> contributes nothing
+                        bool pending = cur_live && cur_cnt != 0;
                         const uint32_t fb = code_bwd(cur.code);
                         if (pending) {
-                            const T rcpb = rcp_in(cur.rcp_bwd, (T)0);
+                            const T rcpb = cur_cnt < 256 ? rinv[cur_cnt] : (T)1 / (T)cur_cnt;   // .cpp:692, :696
 #pragma unroll
                             for (int c = 0; c < COUT; ++c) val[c] *= rcpb;
                         }
@@ -1073,9 +1081,17 @@ __global__ __launch_bounds__(256) void backward_kernel(
                             for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += val[c];
                         }
                         cur = nxt;
-                        nxt = nn;
+                        nxt = nx2;
+                        nx2 = nx3;
+                        cur_live = nxt_live;
+                        cur_cnt = nxt_cnt;
+                        nxt_live = nx2_live;
+                        nxt_cnt = nx2_cnt;
 #pragma unroll
-                        for (int c = 0; c < COUT; ++c) val[c] = nval[c];
+                        for (int c = 0; c < COUT; ++c) {
+                            val[c] = nval[c];
+                            nval[c] = n2val[c];
+                        }
                     }
                     if (CONV3P_ABLATE & 256) G[cq] += ablate_sink;
                 } else {

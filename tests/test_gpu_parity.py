@@ -248,6 +248,95 @@ def test_full_size_matches_oracle_cfg2_layer(dev, cfg2):
     assert rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
 
 
+# ------------------------------------------------------------------ BASELINE configs 4 and 5 at full size
+def test_full_size_cfg5_shard(dev):
+    """BASELINE config 5, one GPU's shard at FULL size: B=16 clouds of N=8192 SceneNN-shaped points, one conv3p
+    layer 128->256, stride 1 (matrix-core path).  neighbour counts exact vs the oracle on 2 clouds; y / dX / dW of
+    cloud 3 against the oracle on channel slices (every output channel of the reference loops is an independent
+    sum -- y over c, dX over k, dW over (k, c) -- so a slice of the filter gives exactly those channels);
+    linearity and batch independence on the whole shard."""
+    B, N, ci, co = 16, 8192, 128, 256
+    s = (1, 1, 1)
+    P = synth.room_like(B, N, 7, extent=(2.4, 2.4, 3.0))
+    X = synth.features(B, N, ci, 8, points=P)
+    W = synth.filter_weights(3, 3, 3, ci, co, 5)
+    dY = synth.upstream_grad(B, N, co, 9)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tp, tx, tw, tdy = t(P), t(X), t(W), t(dY)
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
+    cnt = op.neighbor_count(tp, (3, 3, 3), s, VOX)
+    assert np.array_equal(cnt[:2].cpu().numpy(), oracle.neighbor_count(P[:2], (3, 3, 3), s, VOX))
+    y = op.conv3p(tp, tx, tw, s, VOX, cache=cache)
+    dx, dw = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=cache)
+    b = 3
+    cs, ks = slice(40, 56), slice(100, 108)                          # 16 output channels, 8 input channels
+    y_ref = oracle.forward(P[b:b + 1], X[b:b + 1], W[..., cs], s, VOX)
+    assert rel_err(y[b:b + 1, :, cs].cpu().numpy(), y_ref) <= 1e-5
+    dx_ref, _ = oracle.backward(dY[b:b + 1], P[b:b + 1], X[b:b + 1, :, ks], W[:, :, :, ks, :], s, VOX)
+    assert rel_err(dx[b:b + 1, :, ks].cpu().numpy(), dx_ref) <= 1e-5
+    # grad_filter of cloud b alone (the op called on that cloud), slice (k, c)
+    _, dw_b = op.conv3p_grad(tdy[b:b + 1].contiguous(), tp[b:b + 1].contiguous(), tx[b:b + 1].contiguous(), tw, s, VOX)
+    _, dw_ref = oracle.backward(dY[b:b + 1, :, cs], P[b:b + 1], X[b:b + 1, :, ks], W[:, :, :, ks, cs], s, VOX)
+    assert rel_err(dw_b[:, :, :, ks, cs].cpu().numpy(), dw_ref) <= 2e-5
+    # batch independence: cloud b inside the shard == cloud b alone; grad_filter of the shard == sum over clouds
+    y_b = op.conv3p(tp[b:b + 1].contiguous(), tx[b:b + 1].contiguous(), tw, s, VOX)
+    assert float((y_b[0] - y[b]).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))
+    # linearity in the input on the full shard
+    x2 = torch.randn_like(tx)
+    lin = op.conv3p(tp, 2.0 * tx + x2, tw, s, VOX, cache=cache) - (2.0 * y + op.conv3p(tp, x2, tw, s, VOX, cache=cache))
+    assert float(lin.abs().max()) <= 5e-5 * max(1.0, float(y.abs().max()))
+    # <dY, conv(X)> = <dW, W> = <dX, X> on generic data (float64 accumulation; 2e-3: a few pairs sit on tap edges)
+    lhs = float((tdy.double() * y.double()).sum())
+    assert abs(lhs - float((dw.double() * tw.double()).sum())) <= 2e-3 * max(1.0, abs(lhs))
+    assert abs(lhs - float((dx.double() * tx.double()).sum())) <= 2e-3 * max(1.0, abs(lhs))
+
+
+def test_full_size_cfg4_stack(dev):
+    """BASELINE config 4 at FULL size: the 5-layer S3DIS scene_seg stack (9->9 s1..s4, 36->13 s1) on B=16 room
+    blocks of N=4096.  Clouds 0-1 against the oracle stack; the same two clouds run as a batch of 2 must come out
+    of the full batch bit-for-bit (activations and grad_input; the weight gradient is a sum over the batch)."""
+    B, N, cin, ncls = 16, 4096, 9, 13
+    P = synth.room_like(B, N, 40)
+    X = synth.features(B, N, cin, 50, points=P)
+    up = synth.upstream_grad(B, N, ncls, 60)
+    st = stack.Conv3pStack(cin, ncls, device=dev, seed=3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    acts = st.forward(t(P), t(X))
+    dx, fused = st.backward([t(up)])
+    acts = [a.clone() for a in acts]
+    dx, fused = dx.clone(), fused.clone()
+    st2 = stack.Conv3pStack(cin, ncls, device=dev, seed=3)
+    acts2 = st2.forward(t(P[:2]), t(X[:2]))
+    dx2, fused2 = st2.backward([t(up[:2])])
+    for a, a2 in zip(acts, acts2):
+        assert torch.equal(a[:2], a2)
+    assert torch.equal(dx[:2], dx2)
+    ref_acts, ref_dx, ref_fused = _oracle_stack(P[:2], X[:2], [f.cpu().numpy() for f in st.filters], st.layers,
+                                                [up[:2]], ncls)
+    for a, r in zip(acts2, ref_acts):
+        assert rel_err(a.cpu().numpy(), r) <= 2e-5
+    assert rel_err(dx2.cpu().numpy(), ref_dx) <= 5e-5
+    assert rel_err(fused2.cpu().numpy(), ref_fused) <= 5e-5
+    # the full batch's weight gradient: adjoint identity per layer is covered above; here scale sanity vs 2 clouds
+    assert float(fused.abs().max()) > float(fused2.abs().max()) * 0.5
+
+
+@pytest.mark.parametrize("ci,co,N", [(12, 9, 4096), (36, 41, 2048), (16, 9, 1024)])
+def test_scenenn_model_shapes(dev, ci, co, N):
+    """SceneNN scene_seg shapes (scene_seg/train_scene_seg_scenenn.py:42: 41 classes; scenenn_provider.py:47-59:
+    >= 12 input channels): 12->9 first layer and the 36->41 head, against the oracle, bitwise reproducible."""
+    B = 2
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=1300)
+    s = (1, 1, 1)
+    ref = (oracle.neighbor_count(P, (3, 3, 3), s, VOX), oracle.forward(P, X, W, s, VOX, nthreads=2)) + \
+        oracle.backward(dY, P, X, W, s, VOX, nthreads=1)
+    got = run_hip(dev, P, X, W, dY, s)
+    check_against(ref, got, np.float32)
+    again = run_hip(dev, P, X, W, dY, s)
+    for a, b in zip(got, again):
+        assert np.array_equal(a, b), "model shapes must be bitwise reproducible"
+
+
 # ------------------------------------------------------------------ the models' layer stacks (row A8)
 def _oracle_stack(P, X, filters, layers, ups, num_class):
     acts, x = [], X
