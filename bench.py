@@ -295,6 +295,7 @@ def main():
     tXs = [t.clone() for t in tPs]
     tP, tX = tPs[0], tXs[0]
     ups = [torch.from_numpy(u).to(dev) for u in ups_np]
+    gcat = torch.cat(ups, dim=2).contiguous()      # dL/dconcat (B, N, 36): what the model's dense head hands back
     st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial)
     counter = [0]
     # set-up, not a step: create the RCCL communicator (seconds on the first collective), allocate the stack's
@@ -313,15 +314,13 @@ def main():
         def step():
             i = counter[0] % NBATCH
             counter[0] += 1
-            if pre and os.environ.get("CONV3P_PREFETCH_EARLY"):
-                stk.prefetch(tPs[(i + 1) % NBATCH])
             stk.forward(tPs[i], tXs[i])
-            if pre and not os.environ.get("CONV3P_PREFETCH_EARLY"):
+            if pre:
                 # the next batch's geometry (1 sort + 4 searches) goes to the side stream now and runs under this
                 # batch's backward, as a data-loader-fed training loop would do.  Every step still performs exactly
                 # one full geometry build, one forward and one backward inside the timed region.
                 stk.prefetch(tPs[(i + 1) % NBATCH])
-            dx, fused = stk.backward(ups)
+            dx, fused = stk.backward(gcat)
             distributed.allreduce_weight_grads(fused)
             return dx, fused
         return step

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CONV3P_ABI_VERSION 2
+#define CONV3P_ABI_VERSION 3
 
 /* status codes */
 #define CONV3P_OK 0
@@ -232,6 +232,76 @@ int conv3p_layer_backward_cached_f64(const double *grad_out, const double *point
                                      const double *grad_addend, double *grad_input, double *grad_filter,
                                      void *cache, size_t cache_bytes, const conv3p_cache_config *cfg,
                                      void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The models' conv3p stack as ONE call per pass (not in the reference, which builds it from op calls in Python:
+ * pointcnn2_acsd.py:47-68, scene_seg/pointcnn_scene_seg_acsd.py:51-57).
+ *
+ *   hidden layer l (l = 0 .. n_hidden-1):  act_l = selu(Conv3p(points, act_{l-1}, filter_l, stride_l, voxel)),
+ *       act_{-1} = input (in_channels), every hidden layer has `hidden` output channels;
+ *   concat = [act_0 | act_1 | ...]  (B, N, n_hidden*hidden)       -- pointcnn2_acsd.py:68
+ *   optional head (num_class > 0):  head = selu(Conv3p(points, concat, filter_head, head_stride, voxel))
+ *
+ * What the single call buys over 2 x (n_hidden + 1) op calls: one host crossing per pass; the activations are
+ * written by the layers' epilogues straight into their column block of `concat` and read from there by the next
+ * layer and by the backward (no concat copy, no slice copies); the geometry of all layers is built once per
+ * `points` (on `side_stream`, if given, concurrently with the first layers).
+ * All layers share the filter extents fz,fy,fx; strides[l] = {sx,sy,sz} of hidden layer l, strides[n_hidden] of the
+ * head.  filters / grad_filters are HOST arrays of n_hidden (+1) DEVICE pointers, each tensor laid out as Conv3p's
+ * filter.  `cache` as for the *_cached entry points, with slots >= number of distinct strides.
+ * Shapes outside the register-resident list return CONV3P_ERR_UNSUPPORTED: compose the stack
+ * from the per-op entry points then.
+ * ------------------------------------------------------------------------------------------- */
+#define CONV3P_STACK_MAX_LAYERS 8
+typedef struct conv3p_stack_desc {
+    int n_hidden;      /* hidden layers (4 in both models)                                   */
+    int in_channels;   /* channels of `input`                                                */
+    int hidden;        /* output channels of every hidden layer (9)                          */
+    int num_class;     /* output channels of the head layer, 0 = no head (classification)    */
+    int fz, fy, fx;    /* filter extents of every layer                                      */
+    int32_t strides[CONV3P_STACK_MAX_LAYERS + 1][3];
+} conv3p_stack_desc;
+
+/* bytes of scratch conv3p_stack_backward_* needs (0 for an invalid description) */
+size_t conv3p_stack_scratch_bytes(const conv3p_stack_desc *desc, int elem_bytes, int B, int N);
+
+/* Enqueue the geometry (sort + every layer's neighbour search) of `points` into `cache` on `stream`, ordered after
+ * everything already enqueued on `after_stream` (the stream that produces `points`; may be NULL).  A later
+ * conv3p_stack_forward_* with the same `points` pointer and cache waits for it instead of searching, so the searches
+ * of the NEXT batch can run under the current batch's backward.  The caller must not modify `points` in between. */
+int conv3p_stack_prefetch_f32(const conv3p_stack_desc *desc, const float *points, float voxel_size, int B, int N,
+                              void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream,
+                              void *after_stream);
+int conv3p_stack_prefetch_f64(const conv3p_stack_desc *desc, const double *points, double voxel_size, int B, int N,
+                              void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream,
+                              void *after_stream);
+
+/* concat (B, N, n_hidden*hidden) receives every hidden activation; head_out (B, N, num_class) or NULL. */
+int conv3p_stack_forward_f32(const conv3p_stack_desc *desc, const float *points, const float *input,
+                             const float *const *filters, float voxel_size, int B, int N, float *concat,
+                             float *head_out, void *cache, size_t cache_bytes, const conv3p_cache_config *cfg,
+                             void *stream, void *side_stream);
+int conv3p_stack_forward_f64(const conv3p_stack_desc *desc, const double *points, const double *input,
+                             const double *const *filters, double voxel_size, int B, int N, double *concat,
+                             double *head_out, void *cache, size_t cache_bytes, const conv3p_cache_config *cfg,
+                             void *stream, void *side_stream);
+
+/* Backward of the same stack, after conv3p_stack_forward_* on the same cache and points.
+ *   grad_concat (B, N, n_hidden*hidden): gradient w.r.t. `concat` from its consumer outside the stack (the dense
+ *                head of the classification model); NULL = none.
+ *   grad_head   (B, N, num_class): gradient w.r.t. the head activation (num_class > 0); its contribution to the
+ *                concat is added to grad_concat's.
+ *   grad_input  (B, N, in_channels); grad_filters[l] like filters[l] (e.g. views of one fused all-reduce buffer). */
+int conv3p_stack_backward_f32(const conv3p_stack_desc *desc, const float *points, const float *input,
+                              const float *const *filters, float voxel_size, int B, int N, const float *concat,
+                              const float *head_out, const float *grad_concat, const float *grad_head,
+                              float *grad_input, float *const *grad_filters, void *scratch, size_t scratch_bytes,
+                              void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
+int conv3p_stack_backward_f64(const conv3p_stack_desc *desc, const double *points, const double *input,
+                              const double *const *filters, double voxel_size, int B, int N, const double *concat,
+                              const double *head_out, const double *grad_concat, const double *grad_head,
+                              double *grad_input, double *const *grad_filters, void *scratch, size_t scratch_bytes,
+                              void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
 
 /* Kernel-level timing with HIP events recorded on the caller's stream (bench.py uses it
  * to derive the roofline of the dominant kernel).  Off by default; when enabled every

@@ -20,7 +20,8 @@ PASS_FORWARD = 0
 PASS_BACKWARD = 1
 PASS_NEIGHBOR_COUNT = 2
 CACHE_POINTS_UNCHANGED = 1
-ABI_VERSION = 2                # CONV3P_ABI_VERSION of include/conv3p.h
+ABI_VERSION = 3                # CONV3P_ABI_VERSION of include/conv3p.h
+STACK_MAX_LAYERS = 8
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -42,6 +43,10 @@ def _sig(real):
         "selu": (_i, [_vp, _vp, _sz, _vp]),
         "selu_grad": (_i, [_vp, _vp, _vp, _sz, _vp]),
         "selu_grad_add": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+        "stack_prefetch": (_i, [ctypes.POINTER(StackDesc), _vp, real, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+        "stack_forward": (_i, [ctypes.POINTER(StackDesc), _vp, _vp, _vp, real, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+        "stack_backward": (_i, [ctypes.POINTER(StackDesc), _vp, _vp, _vp, real, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _sz, _vp, _sz, _vp, _vp]),
     }
 
 
@@ -51,7 +56,14 @@ class CacheConfig(ctypes.Structure):
                 ("flags", _i)]
 
 
+class StackDesc(ctypes.Structure):
+    """conv3p_stack_desc of include/conv3p.h."""
+    _fields_ = [("n_hidden", _i), ("in_channels", _i), ("hidden", _i), ("num_class", _i), ("fz", _i), ("fy", _i),
+                ("fx", _i), ("strides", (ctypes.c_int32 * 3) * (STACK_MAX_LAYERS + 1))]
+
+
 SYMBOLS = {
+    "conv3p_stack_scratch_bytes": (_sz, [ctypes.POINTER(StackDesc), _i, _i, _i]),
     "conv3p_workspace_bytes": (_sz, [_i] * 9),
     "conv3p_cache_bytes": (_sz, [_i, _i, _i, ctypes.POINTER(CacheConfig)]),
     "conv3p_cache_forget": (_i, [_vp]),

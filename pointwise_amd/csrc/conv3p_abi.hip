@@ -278,6 +278,8 @@ size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPer
     return 0;
 }
 
+bool cache_cfg_ok(const conv3p_cache_config *cfg);
+
 int hip_ok()
 {
     return hipGetLastError() == hipSuccess ? CONV3P_OK : CONV3P_ERR_LAUNCH;
@@ -305,7 +307,22 @@ template <typename T> struct Call {
     // backward: grad_input = (dX + addend) * selu'(input)
     bool act = false;
     const T *addend = nullptr;
+    RowLd ld{0, 0, 0, 0, 0};       // row strides of the feature tensors; filled with the dense values by set_ld()
+    bool strided = false;          // some tensor is a column block of a wider buffer (register-path shapes only)
 };
+
+template <typename T> void set_ld(Call<T> &c, const RowLd *ld, int Cin, int Cout)
+{
+    c.ld = RowLd{Cin, Cout, Cout, Cin, Cin};
+    if (ld) {
+        if (ld->in > 0) c.ld.in = ld->in;
+        if (ld->out > 0) c.ld.out = ld->out;
+        if (ld->dy > 0) c.ld.dy = ld->dy;
+        if (ld->dx > 0) c.ld.dx = ld->dx;
+        if (ld->add > 0) c.ld.add = ld->add;
+    }
+    c.strided = c.ld.in != Cin || c.ld.out != Cout || c.ld.dy != Cout || c.ld.dx != Cin || c.ld.add != Cin;
+}
 
 template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned long long tag, uint32_t epoch, int force)
 {
@@ -397,7 +414,6 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
-    const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
     const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * ((CI * CO) | 1) * sizeof(T)) : 0) +
                        a16((size_t)st.ntap * kCntStride * sizeof(T)) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
@@ -409,7 +425,7 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, d.Cin, d.Cout,
-                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0, st.window ? c.L.cmin : nullptr, S.tcount);
+                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0, st.window ? c.L.cmin : nullptr, S.tcount, c.ld);
     return hip_ok();
 }
 
@@ -434,7 +450,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
-                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr);
+                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr, c.ld);
     return hip_ok();
 }
 
@@ -603,6 +619,11 @@ struct CacheHost {
     uint64_t clock = 0;
     uint64_t gen = 0;                  // bumped by every call that does not carry CONV3P_CACHE_POINTS_UNCHANGED
     uint32_t epoch = 0;
+    // conv3p_stack_prefetch_*: geometry of `pending_points` enqueued on another stream; ready[l] fires when layer
+    // l's lists are complete
+    const void *pending_points = nullptr;
+    int pending_layers = 0;
+    std::vector<hipEvent_t> ready;
 };
 std::mutex g_cache_mu;
 std::map<void *, CacheHost> g_caches;
@@ -644,7 +665,10 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     CacheHost &h = g_caches[wh.buf];
     if (h.B != d.B || h.N != d.N || h.elem != (int)sizeof(T) || h.ntap_max != ntap_max || h.nslots != wh.nslots ||
         h.ppp != wh.ppp) {
+        std::vector<hipEvent_t> keep;
+        keep.swap(h.ready);            // the stack-level entry points' events outlive a re-shape of the cache
         h = CacheHost();
+        h.ready.swap(keep);
         h.B = d.B; h.N = d.N; h.elem = (int)sizeof(T); h.ntap_max = ntap_max; h.nslots = wh.nslots; h.ppp = wh.ppp;
         h.tags.assign(wh.nslots, 0ull);
         h.stamp.assign(wh.nslots, 0ull);
@@ -675,12 +699,14 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
 }
 
 template <typename T> int selu_impl(const T *x, T *y, size_t n, void *stream);
-template <typename T> int selu_grad_impl(const T *y, const T *dy, const T *dy_b, T *dx, size_t n, void *stream);
+// rows x cols values; lds = {ld_y, ld_dy, ld_b, ld_dx} or nullptr for dense operands
+template <typename T>
+int selu_grad_impl(const T *y, const T *dy, const T *dy_b, T *dx, size_t rows, int cols, const int *lds, void *stream);
 
 template <typename T>
 int forward_impl(const T *points, const T *input, const T *filter, const int32_t *stride, T voxel, int B,
                  int N, int Cin, int Cout, int fz, int fy, int fx, T *output, const Where &wh, void *stream,
-                 bool act = false)
+                 bool act = false, const RowLd *ldp = nullptr)
 {
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     TRY(check(d, stride, (double)voxel, true));
@@ -691,6 +717,8 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     if (Cin == 0) return zero_async(output, out_elems * sizeof(T), s);   // empty contraction; selu(0) == 0
     Call<T> c;
     c.act = act;
+    set_ld(c, ldp, Cin, Cout);
+    if (c.strided && !small_shape((int)sizeof(T), Cin, Cout)) return CONV3P_ERR_UNSUPPORTED;   // dense tensors only
     TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_cloud_min<T>(points, c));
@@ -702,6 +730,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     }
     CONV3P_SMALL_SHAPES(X)
 #undef X
+    if (c.strided) return CONV3P_ERR_UNSUPPORTED;   // (a register-path shape whose LDS did not fit)
     if constexpr (sizeof(T) == 4) {
         if (c.L.ngroups == 1 && c.deep_scratch_ok) {
 #define X(ci, co)                                                                                    \
@@ -792,7 +821,7 @@ template <typename T>
 int backward_impl(const T *grad_out, const T *points, const T *input, const T *filter,
                   const int32_t *stride, T voxel, int B, int N, int Cin, int Cout, int fz, int fy, int fx,
                   T *grad_input, T *grad_filter, const Where &wh, void *stream, bool act = false,
-                  const T *addend = nullptr)
+                  const T *addend = nullptr, const RowLd *ldp = nullptr)
 {
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     TRY(check(d, stride, (double)voxel, true));
@@ -800,12 +829,13 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     const size_t nw = (size_t)d.ntap * Cin * Cout;
     const size_t dx_elems = (size_t)B * N * Cin;
     if ((dx_elems && !grad_input) || (nw && !grad_filter)) return CONV3P_ERR_INVALID_ARGUMENT;
+    if (ldp && (dx_elems == 0 || Cout == 0)) return CONV3P_ERR_UNSUPPORTED;
     if (dx_elems == 0 || Cout == 0) {                                    // nothing to accumulate
         TRY(zero_async(grad_input, dx_elems * sizeof(T), s));            // .cpp:580
         TRY(zero_async(grad_filter, nw * sizeof(T), s));                 // .cpp:590
         if (act && dx_elems && addend) {
             if (!input) return CONV3P_ERR_INVALID_ARGUMENT;
-            return selu_grad_impl<T>(input, addend, nullptr, grad_input, dx_elems, stream);
+            return selu_grad_impl<T>(input, addend, nullptr, grad_input, (size_t)B * N, Cin, nullptr, stream);
         }
         return CONV3P_OK;
     }
@@ -813,6 +843,8 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     Call<T> c;
     c.act = act;
     c.addend = addend;
+    set_ld(c, ldp, Cin, Cout);
+    if (c.strided && !small_shape((int)sizeof(T), Cin, Cout)) return CONV3P_ERR_UNSUPPORTED;   // dense tensors only
     TRY(begin_call<T>(c, d, stride, voxel, backward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_cloud_min<T>(points, c));
@@ -830,13 +862,14 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
         int drc = deep_backward<ci, co>(c, grad_out, input, filter, grad_input, grad_filter);        \
         if (drc != CONV3P_ERR_UNSUPPORTED)                                                           \
             return drc != CONV3P_OK || !act ? drc                                                    \
-                       : selu_grad_impl<T>(input, grad_input, addend, grad_input, dx_elems, stream); \
+                       : selu_grad_impl<T>(input, grad_input, addend, grad_input, (size_t)B * N, Cin, nullptr, stream); \
     }
             CONV3P_DEEP_SHAPES(X)
 #undef X
         }
     }
     bool generic = false;
+    if (rc == CONV3P_ERR_UNSUPPORTED && c.strided) return rc;
     if (rc == CONV3P_ERR_UNSUPPORTED) {
         generic = true;
         nslots = generic_slots(d, (int)sizeof(T));
@@ -853,7 +886,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     }
     TRY(hip_ok());
     if (act && generic)   // generic path has no fused epilogue
-        return selu_grad_impl<T>(input, grad_input, addend, grad_input, dx_elems, stream);
+        return selu_grad_impl<T>(input, grad_input, addend, grad_input, (size_t)B * N, Cin, nullptr, stream);
     return CONV3P_OK;
 }
 
@@ -884,14 +917,17 @@ template <typename T> int selu_impl(const T *x, T *y, size_t n, void *stream)
     hipLaunchKernelGGL(selu_kernel<T>, dim3(grid), dim3(256), 0, s, x, y, n);
     return hip_ok();
 }
-template <typename T> int selu_grad_impl(const T *y, const T *dy, const T *dy_b, T *dx, size_t n, void *stream)
+template <typename T>
+int selu_grad_impl(const T *y, const T *dy, const T *dy_b, T *dx, size_t rows, int cols, const int *lds, void *stream)
 {
+    const size_t n = rows * (size_t)cols;
     if (n == 0) return CONV3P_OK;
     if (!y || !dy || !dx) return CONV3P_ERR_INVALID_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Scope sc(K_SELU_GRAD, s);
     const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(selu_grad_kernel<T>, dim3(grid), dim3(256), 0, s, y, dy, dy_b, dx, n);
+    hipLaunchKernelGGL(selu_grad_kernel<T>, dim3(grid), dim3(256), 0, s, y, dy, dy_b, dx, rows, cols,
+                       lds ? lds[0] : cols, lds ? lds[1] : cols, lds ? lds[2] : cols, lds ? lds[3] : cols);
     return hip_ok();
 }
 
@@ -936,6 +972,180 @@ Where persistent(int elem, int B, int N, void *cache, size_t bytes, int slots, i
                  cache_scratch_bytes(elem, B, N, max_taps, max_Cin, max_Cout, ppp > 0 ? ppp : kDefaultPairsPerPoint), flags};
 }
 
+
+// ----------------------------------------------------------------------------- the models' stack in one call
+bool stack_desc_ok(const conv3p_stack_desc *sd)
+{
+    if (!sd || sd->n_hidden < 1 || sd->n_hidden > CONV3P_STACK_MAX_LAYERS || sd->in_channels < 1 || sd->hidden < 1 ||
+        sd->num_class < 0 || sd->fz < 1 || sd->fy < 1 || sd->fx < 1)
+        return false;
+    for (int l = 0; l < sd->n_hidden + (sd->num_class > 0 ? 1 : 0); ++l)
+        for (int a = 0; a < 3; ++a)
+            if (sd->strides[l][a] < 1) return false;
+    return true;
+}
+inline int stack_layers(const conv3p_stack_desc *sd) { return sd->n_hidden + (sd->num_class > 0 ? 1 : 0); }
+
+// geometry of every layer on `s`, ordered after `after`; one event per layer in the cache's host record
+template <typename T>
+int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B, int N, void *cache, size_t cache_bytes,
+                   const conv3p_cache_config *cfg, hipStream_t s, hipStream_t after, bool differs)
+{
+    const int nl = stack_layers(sd);
+    std::vector<hipEvent_t> ev;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        CacheHost &h = g_caches[cache];
+        while ((int)h.ready.size() < nl + 1) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CONV3P_ERR_LAUNCH;
+            h.ready.push_back(e);
+        }
+        ev = h.ready;
+    }
+    if (differs) {   // `points` is produced on another stream
+        if (hipEventRecord(ev[nl], after) != hipSuccess || hipStreamWaitEvent(s, ev[nl], 0) != hipSuccess)
+            return CONV3P_ERR_LAUNCH;
+    }
+    for (int l = 0; l < nl; ++l) {
+        conv3p_cache_config c2 = *cfg;
+        c2.flags = l > 0 ? CONV3P_CACHE_POINTS_UNCHANGED : 0;
+        const Where wh = persistent((int)sizeof(T), B, N, cache, cache_bytes, c2.slots, c2.max_taps, c2.pairs_per_point,
+                                    c2.max_Cin, c2.max_Cout, c2.flags);
+        TRY(prepare_impl<T>(points, sd->strides[l], voxel, B, N, sd->fz, sd->fy, sd->fx, wh, s));
+        if (hipEventRecord(ev[l], s) != hipSuccess) return CONV3P_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CacheHost &h = g_caches[cache];
+    h.pending_points = points;
+    h.pending_layers = nl;
+    return CONV3P_OK;
+}
+
+template <typename T>
+int stack_prefetch_impl(const conv3p_stack_desc *sd, const T *points, T voxel, int B, int N, void *cache,
+                        size_t cache_bytes, const conv3p_cache_config *cfg, void *stream, void *after_stream)
+{
+    if (!stack_desc_ok(sd) || !cache_cfg_ok(cfg)) return CONV3P_ERR_INVALID_ARGUMENT;
+    if ((size_t)B * N == 0) return CONV3P_OK;
+    if (!points) return CONV3P_ERR_INVALID_ARGUMENT;
+    return stack_geometry<T>(sd, points, voxel, B, N, cache, cache_bytes, cfg, static_cast<hipStream_t>(stream),
+                             static_cast<hipStream_t>(after_stream), after_stream != stream);
+}
+
+template <typename T>
+int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *input, const T *const *filters, T voxel,
+                       int B, int N, T *concat, T *head_out, void *cache, size_t cache_bytes,
+                       const conv3p_cache_config *cfg, void *stream, void *side_stream)
+{
+    if (!stack_desc_ok(sd) || !cache_cfg_ok(cfg) || !filters) return CONV3P_ERR_INVALID_ARGUMENT;
+    if ((size_t)B * N == 0) return CONV3P_OK;
+    if (!points || !input || !concat || (sd->num_class > 0 && !head_out)) return CONV3P_ERR_INVALID_ARGUMENT;
+    const int nl = stack_layers(sd), CW = sd->n_hidden * sd->hidden;
+    hipStream_t main = static_cast<hipStream_t>(stream);
+    // geometry: already enqueued by conv3p_stack_prefetch_* for these points, or enqueued now on the side stream
+    // (each layer's search then runs while the previous layers accumulate), or built inline by the op calls
+    bool events = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_caches.find(cache);
+        if (it != g_caches.end() && it->second.pending_points == points && it->second.pending_layers == nl) events = true;
+        if (it != g_caches.end()) it->second.pending_points = nullptr;
+    }
+    if (!events && side_stream != nullptr && side_stream != stream) {
+        TRY(stack_geometry<T>(sd, points, voxel, B, N, cache, cache_bytes, cfg, static_cast<hipStream_t>(side_stream), main, true));
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_caches[cache].pending_points = nullptr;
+        events = true;
+    }
+    std::vector<hipEvent_t> ev;
+    if (events) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        ev = g_caches[cache].ready;
+    }
+    for (int l = 0; l < nl; ++l) {
+        if (events && hipStreamWaitEvent(main, ev[l], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
+        conv3p_cache_config c2 = *cfg;
+        c2.flags = (l > 0 || events) ? CONV3P_CACHE_POINTS_UNCHANGED : 0;   // the first call of a step re-validates
+        const bool head = l == sd->n_hidden;
+        const int Cin = head ? CW : (l == 0 ? sd->in_channels : sd->hidden);
+        const int Cout = head ? sd->num_class : sd->hidden;
+        const T *x = head ? concat : (l == 0 ? input : concat + (size_t)sd->hidden * (l - 1));
+        T *y = head ? head_out : concat + (size_t)sd->hidden * l;
+        const RowLd ld{head ? CW : (l == 0 ? sd->in_channels : CW), head ? sd->num_class : CW, 0, 0, 0};
+        const Where wh = persistent((int)sizeof(T), B, N, cache, cache_bytes, c2.slots, c2.max_taps, c2.pairs_per_point,
+                                    c2.max_Cin, c2.max_Cout, c2.flags);
+        if (!filters[l]) return CONV3P_ERR_INVALID_ARGUMENT;
+        TRY(forward_impl<T>(points, x, filters[l], sd->strides[l], voxel, B, N, Cin, Cout, sd->fz, sd->fy, sd->fx, y, wh,
+                            stream, /*act=*/true, &ld));
+    }
+    return CONV3P_OK;
+}
+
+template <typename T> size_t stack_scratch_bytes(const conv3p_stack_desc *sd, int B, int N)
+{
+    const size_t rows = (size_t)B * N;
+    const size_t wide = (size_t)(sd->hidden > sd->num_class ? sd->hidden : sd->num_class);
+    // two ping-pong gradient buffers + the head's gradient w.r.t. the concat
+    return up(rows * wide * sizeof(T)) * 2 + up(rows * (size_t)sd->n_hidden * sd->hidden * sizeof(T));
+}
+
+template <typename T>
+int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *input, const T *const *filters, T voxel,
+                        int B, int N, const T *concat, const T *head_out, const T *grad_concat, const T *grad_head,
+                        T *grad_input, T *const *grad_filters, void *scratch, size_t scratch_bytes, void *cache,
+                        size_t cache_bytes, const conv3p_cache_config *cfg, void *stream)
+{
+    if (!stack_desc_ok(sd) || !cache_cfg_ok(cfg) || !filters || !grad_filters) return CONV3P_ERR_INVALID_ARGUMENT;
+    if ((size_t)B * N == 0) return CONV3P_OK;   // (grad_filters of an empty batch are the caller's zeros)
+    const bool has_head = sd->num_class > 0;
+    if (!points || !input || !concat || !grad_input || (has_head && (!head_out || !grad_head)) ||
+        (!has_head && !grad_concat))
+        return CONV3P_ERR_INVALID_ARGUMENT;
+    TRY(buf_check(scratch, scratch_bytes, stack_scratch_bytes<T>(sd, B, N)));
+    const size_t rows = (size_t)B * N;
+    const int H = sd->hidden, CW = sd->n_hidden * H, nh = sd->n_hidden;
+    const size_t wide = (size_t)(H > sd->num_class ? H : sd->num_class);
+    char *sp = static_cast<char *>(scratch);
+    T *ga = reinterpret_cast<T *>(sp);
+    T *gb = reinterpret_cast<T *>(sp + up(rows * wide * sizeof(T)));
+    T *dconcat = reinterpret_cast<T *>(sp + 2 * up(rows * wide * sizeof(T)));
+    auto where = [&]() {
+        return persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
+                          cfg->max_Cin, cfg->max_Cout, CONV3P_CACHE_POINTS_UNCHANGED);
+    };
+    // external gradient of the concat's column blocks: the caller's, the head's, or their sum
+    const T *ext = grad_concat;
+    int ld_ext = CW;
+    if (has_head) {
+        // g = dL/d(head conv output) = grad_head * selu'(head_out)
+        TRY(selu_grad_impl<T>(head_out, grad_head, nullptr, ga, rows, sd->num_class, nullptr, stream));
+        TRY(backward_impl<T>(ga, points, concat, filters[nh], sd->strides[nh], voxel, B, N, CW, sd->num_class, sd->fz,
+                             sd->fy, sd->fx, dconcat, grad_filters[nh], where(), stream));
+        if (grad_concat) {   // both consumers: dconcat += grad_concat  (slope 1: reuse the fused add with y = +1 ...)
+            return CONV3P_ERR_UNSUPPORTED;   // not needed by either model; keep the contract honest
+        }
+        ext = dconcat;
+    }
+    // g_l = dL/d(conv output of hidden layer l).  Last hidden layer: only the external gradient reaches its activation.
+    T *g = has_head ? gb : ga, *gn = has_head ? ga : gb;
+    {
+        const int lds[4] = {CW, ld_ext, 0, H};
+        TRY(selu_grad_impl<T>(concat + (size_t)H * (nh - 1), ext + (size_t)H * (nh - 1), nullptr, g, rows, H, lds, stream));
+    }
+    for (int l = nh - 1; l >= 1; --l) {
+        // grad wrt the argument of the SELU that produced act_{l-1}: (dX + ext_{l-1}) * selu'(act_{l-1})
+        const RowLd ld{CW, 0, H, H, ld_ext};
+        const int Cin = H;
+        TRY(backward_impl<T>(g, points, concat + (size_t)H * (l - 1), filters[l], sd->strides[l], voxel, B, N, Cin, H,
+                             sd->fz, sd->fy, sd->fx, gn, grad_filters[l], where(), stream, /*act=*/true,
+                             ext + (size_t)H * (l - 1), &ld));
+        T *t = g; g = gn; gn = t;
+    }
+    return backward_impl<T>(g, points, input, filters[0], sd->strides[0], voxel, B, N, sd->in_channels, H, sd->fz, sd->fy,
+                            sd->fx, grad_input, grad_filters[0], where(), stream);
+}
+
 bool cache_cfg_ok(const conv3p_cache_config *cfg)
 {
     return cfg && cfg->slots > 0 && cfg->slots <= 64 && cfg->max_taps > 0 && cfg->max_taps < (int)kNoTap &&
@@ -971,7 +1181,11 @@ size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_confi
 int conv3p_cache_forget(void *cache)
 {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    g_caches.erase(cache);
+    auto it = g_caches.find(cache);
+    if (it != g_caches.end()) {
+        for (hipEvent_t e : it->second.ready) (void)hipEventDestroy(e);
+        g_caches.erase(it);
+    }
     return CONV3P_OK;
 }
 
@@ -1099,24 +1313,59 @@ int conv3p_selu_f32(const float *x, float *y, size_t n, void *stream) { return s
 int conv3p_selu_f64(const double *x, double *y, size_t n, void *stream) { return selu_impl<double>(x, y, n, stream); }
 int conv3p_selu_grad_f32(const float *y, const float *dy, float *dx, size_t n, void *stream)
 {
-    return selu_grad_impl<float>(y, dy, nullptr, dx, n, stream);
+    return selu_grad_impl<float>(y, dy, nullptr, dx, n, 1, nullptr, stream);
 }
 int conv3p_selu_grad_f64(const double *y, const double *dy, double *dx, size_t n, void *stream)
 {
-    return selu_grad_impl<double>(y, dy, nullptr, dx, n, stream);
+    return selu_grad_impl<double>(y, dy, nullptr, dx, n, 1, nullptr, stream);
 }
 int conv3p_selu_grad_add_f32(const float *y, const float *dy_a, const float *dy_b, float *dx, size_t n,
                              void *stream)
 {
     if (n && !dy_b) return CONV3P_ERR_INVALID_ARGUMENT;
-    return selu_grad_impl<float>(y, dy_a, dy_b, dx, n, stream);
+    return selu_grad_impl<float>(y, dy_a, dy_b, dx, n, 1, nullptr, stream);
 }
 int conv3p_selu_grad_add_f64(const double *y, const double *dy_a, const double *dy_b, double *dx, size_t n,
                              void *stream)
 {
     if (n && !dy_b) return CONV3P_ERR_INVALID_ARGUMENT;
-    return selu_grad_impl<double>(y, dy_a, dy_b, dx, n, stream);
+    return selu_grad_impl<double>(y, dy_a, dy_b, dx, n, 1, nullptr, stream);
 }
+
+size_t conv3p_stack_scratch_bytes(const conv3p_stack_desc *desc, int elem_bytes, int B, int N)
+{
+    if (!stack_desc_ok(desc) || B < 0 || N < 0 || (elem_bytes != 4 && elem_bytes != 8)) return 0;
+    const size_t b = elem_bytes == 4 ? stack_scratch_bytes<float>(desc, B, N) : stack_scratch_bytes<double>(desc, B, N);
+    return b ? b : kAlign;
+}
+#define STACK_ENTRY(SFX, T)                                                                                         \
+    int conv3p_stack_prefetch_##SFX(const conv3p_stack_desc *desc, const T *points, T voxel_size, int B, int N,     \
+                                    void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream,  \
+                                    void *after_stream)                                                             \
+    {                                                                                                               \
+        return stack_prefetch_impl<T>(desc, points, voxel_size, B, N, cache, cache_bytes, cfg, stream,              \
+                                      after_stream);                                                                \
+    }                                                                                                               \
+    int conv3p_stack_forward_##SFX(const conv3p_stack_desc *desc, const T *points, const T *input,                  \
+                                   const T *const *filters, T voxel_size, int B, int N, T *concat, T *head_out,     \
+                                   void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream,   \
+                                   void *side_stream)                                                               \
+    {                                                                                                               \
+        return stack_forward_impl<T>(desc, points, input, filters, voxel_size, B, N, concat, head_out, cache,       \
+                                     cache_bytes, cfg, stream, side_stream);                                        \
+    }                                                                                                               \
+    int conv3p_stack_backward_##SFX(const conv3p_stack_desc *desc, const T *points, const T *input,                 \
+                                    const T *const *filters, T voxel_size, int B, int N, const T *concat,           \
+                                    const T *head_out, const T *grad_concat, const T *grad_head, T *grad_input,     \
+                                    T *const *grad_filters, void *scratch, size_t scratch_bytes, void *cache,       \
+                                    size_t cache_bytes, const conv3p_cache_config *cfg, void *stream)               \
+    {                                                                                                               \
+        return stack_backward_impl<T>(desc, points, input, filters, voxel_size, B, N, concat, head_out,             \
+                                      grad_concat, grad_head, grad_input, grad_filters, scratch, scratch_bytes,     \
+                                      cache, cache_bytes, cfg, stream);                                             \
+    }
+STACK_ENTRY(f32, float)
+STACK_ENTRY(f64, double)
 
 int conv3p_profile_enable(int on)
 {

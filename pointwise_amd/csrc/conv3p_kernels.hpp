@@ -32,6 +32,17 @@ namespace conv3p {
 // or recycled buffer can only cost a rebuild, never a wrong result.
 // force != 0 (the stateless entry points): ignore the buffer's history and rebuild.
 // ---------------------------------------------------------------------------------
+// Row strides (in elements) of the feature tensors of one op call; the reference's tensors are dense (stride =
+// channel count), the stack-level entry points let a layer read / write a column block of a wider buffer (the
+// (B, N, 36) concat of the models, pointcnn2_acsd.py:68) without a copy.
+struct RowLd {
+    int in;    // input rows                      (forward, backward)
+    int out;   // output rows                     (forward)
+    int dy;    // grad_out rows                   (backward)
+    int dx;    // grad_input rows                 (backward)
+    int add;   // grad_addend rows                (backward, fused SELU-gradient epilogue)
+};
+
 struct CacheCtl {
     unsigned long long *hash;        // [B]
     uint32_t *version;               // [B]
@@ -664,7 +675,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged,
     int act,   // act != 0 (small path only): store selu(out), the models' layer (pointcnn2_acsd.py:48-49)
     const T *__restrict__ cmin,   // per-cloud grid origin (window-mode stencils, overflow path only)
-    const int32_t *__restrict__ tcount)   // populations tile-major [tile][tap][centre lane] (search_tile)
+    const int32_t *__restrict__ tcount,   // populations tile-major [tile][tap][centre lane] (search_tile)
+    RowLd ld)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -751,8 +763,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         __syncthreads();
     }
 
-    const T *in_cloud = input + (size_t)b * N * cin;
-    T *out_cloud = output + (size_t)b * N * cout;
+    const T *in_cloud = input + (size_t)b * N * ld.in;
+    T *out_cloud = output + (size_t)b * N * ld.out;
     T acc[kSmall ? COUT : 1];
     if (kSmall) {
 #pragma unroll
@@ -761,7 +773,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     // centre = lane `ql` (always this lane on the small path)
     auto accumulate = [&](uint32_t cand, uint32_t f, uint32_t ql, T rcp) {
         // rcp = 1 / (T)fsize (.cpp:483): from the pair record (fp32) or from the populations in LDS
-        const T *xr = in_cloud + (size_t)cand * cin;
+        const T *xr = in_cloud + (size_t)cand * ld.in;
         if constexpr (kSmall) {
             T xs[CIN];
             RowLoader<T, CIN>::load(xr, xs);
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 for (int c = 0; c < COUT; ++c) acc[c] = fma_t(wf[k * COUT + c], xs[k], acc[c]);
         } else {
             const T *wf = filter + (size_t)f * cin * cout;
-            T *orow = out_cloud + (size_t)qorig[ql] * cout;
+            T *orow = out_cloud + (size_t)qorig[ql] * ld.out;
             for (int c = 0; c < cout; ++c) {
                 T a = (T)0;
                 for (int k = 0; k < cin; ++k) a = fma_t(wf[(size_t)k * cout + c], xr[k] * rcp, a);
@@ -833,7 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 T v = acc[c];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (sub == 0 && orig >= 0) out_cloud[(size_t)orig * COUT + c] = act ? selu_value(v) : v;
+                if (sub == 0 && orig >= 0) out_cloud[(size_t)orig * ld.out + c] = act ? selu_value(v) : v;
             }
         } else {
             // overflow path ran lane = centre in every wave: fixed-order sum of the per-wave partial rows
@@ -845,7 +857,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 T sum = red[((size_t)0 * COUT + c) * 64 + lane];
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * COUT + c) * 64 + lane];
-                if (me.idx >= 0) out_cloud[(size_t)me.idx * COUT + c] = act ? selu_value(sum) : sum;
+                if (me.idx >= 0) out_cloud[(size_t)me.idx * ld.out + c] = act ? selu_value(sum) : sum;
             }
         }
     }
@@ -879,7 +891,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
                                              // (dX + addend) * selu'(input), the gradient w.r.t. that SELU's argument
     int gen_slots,                           // generic path: number of grad_filter partial slots the workgroups
                                              // spread their atomics over (slot = workgroup % gen_slots)
-    const T *__restrict__ cmin)              // per-cloud grid origin (window-mode stencils, overflow path only)
+    const T *__restrict__ cmin,              // per-cloud grid origin (window-mode stencils, overflow path only)
+    RowLd ld)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -940,7 +953,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     if (wave == 0) {
         qorig[lane] = me.idx;
         if (kSmall) {
-            const T *xr = input + ((size_t)(live ? b : 0) * N + (me.idx < 0 ? 0 : me.idx)) * cin;
+            const T *xr = input + ((size_t)(live ? b : 0) * N + (me.idx < 0 ? 0 : me.idx)) * ld.in;
 #pragma unroll
             for (int k = 0; k < (kSmall ? CIN : 1); ++k) xt[lane * cin + k] = me.idx >= 0 ? xr[k] : (T)0;
         }
@@ -949,9 +962,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
 
     if (live) {
         const int32_t *cnt_cloud = count + (size_t)b * N * st.ntap;
-        const T *dy_cloud = grad_out + (size_t)b * N * cout;
-        const T *in_cloud = input + (size_t)b * N * cin;
-        T *dx_cloud = grad_input + (size_t)b * N * cin;
+        const T *dy_cloud = grad_out + (size_t)b * N * ld.dy;
+        const T *in_cloud = input + (size_t)b * N * ld.in;
+        T *dx_cloud = grad_input + (size_t)b * N * ld.dx;
         // phase A.  Small path: lane = centre `ql` == lane; wave w owns the taps f' == w (mod 4), so
         // every G element has exactly one writer and plain LDS read-modify-write is race-free.
         auto accumulate = [&](uint32_t cand, uint32_t fb, uint32_t ql, T rcp) {
@@ -961,7 +974,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 if (cn == 0) return;                                          // .cpp:679
                 rcp = (T)1 / (T)cn;
             }
-            const T *dyr = dy_cloud + (size_t)cand * cout;
+            const T *dyr = dy_cloud + (size_t)cand * ld.dy;
             if constexpr (kSmall) {
                 T *grow = G + ((size_t)fb * COUT) * kCntStride + ql;
 #pragma unroll
@@ -973,8 +986,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 const int jo = qorig[ql];
                 const T *wf = filter + (size_t)fb * cin * cout;
                 T *dwf = partials + (size_t)(blockIdx.x % (unsigned)gen_slots) * nw + (size_t)fb * cin * cout;
-                const T *xr = in_cloud + (size_t)jo * cin;
-                T *dxr = dx_cloud + (size_t)jo * cin;
+                const T *xr = in_cloud + (size_t)jo * ld.in;
+                T *dxr = dx_cloud + (size_t)jo * ld.dx;
                 for (int k = 0; k < cin; ++k) {
                     const T xk = xr[k];
                     T a = (T)0;
@@ -1018,15 +1031,15 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     T val[COUT], nval[COUT];
                     bool cur_live = live_rec(cur, sub), nxt_live = live_rec(nxt, sub + 4);
                     int cur_cnt = cnt_of(cur, cur_live), nxt_cnt = cnt_of(nxt, nxt_live);
-                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(cur_live ? cur.cand : 0) * COUT, val);
-                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(nxt_live ? nxt.cand : 0) * COUT, nval);
+                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(cur_live ? cur.cand : 0) * ld.dy, val);
+                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(nxt_live ? nxt.cand : 0) * ld.dy, nval);
                     T ablate_sink = (T)0;
                     for (uint32_t i = sub; __any(i < sg.y); i += 4) {
                         const PairEntry nx3 = pe[i + 12 < sg.y ? i + 12 : 0];
                         T n2val[COUT];
                         const bool nx2_live = live_rec(nx2, i + 8);
                         const int nx2_cnt = cnt_of(nx2, nx2_live);
-                        RowLoader<T, COUT>::load(dy_cloud + (size_t)(nx2_live ? nx2.cand : 0) * COUT, n2val);
+                        RowLoader<T, COUT>::load(dy_cloud + (size_t)(nx2_live ? nx2.cand : 0) * ld.dy, n2val);
                         // false positive, hole, or empty tap (.cpp:679) -> contributes nothing
                         bool pending = cur_live && cur_cnt != 0;
                         const uint32_t fb = code_bwd(cur.code);
@@ -1184,9 +1197,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
                 if (me.idx >= 0) {
-                    const size_t o = ((size_t)b * N + me.idx) * CIN + k;
-                    if (act) sum = (addend ? sum + addend[o] : sum) * selu_slope(input[o]);
-                    grad_input[o] = sum;
+                    const size_t r = (size_t)b * N + me.idx;
+                    if (act) sum = (addend ? sum + addend[r * ld.add + k] : sum) * selu_slope(input[r * ld.in + k]);
+                    grad_input[r * ld.dx + k] = sum;
                 }
             }
     }
@@ -1230,13 +1243,29 @@ __global__ __launch_bounds__(256) void selu_kernel(const T *x, T *y, size_t n)  
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] = selu_value(x[i]);
 }
+// dx = (dy [+ dy_b]) * selu'(y) over `rows` rows of `cols` values; every operand has its own row stride, so that
+// the operands may be column blocks of wider buffers (dx may alias dy).
 template <typename T>
-__global__ __launch_bounds__(256) void selu_grad_kernel(const T *y, const T *dy, const T *dy_b, T *dx,
-                                                        size_t n)   // dx may alias dy
+__global__ __launch_bounds__(256) void selu_grad_kernel(const T *y, const T *dy, const T *dy_b, T *dx, size_t rows,
+                                                        int cols, int ld_y, int ld_dy, int ld_b, int ld_dx)
 {
+    const size_t n = rows * (size_t)cols;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const T g = dy_b ? dy[i] + dy_b[i] : dy[i];
-        dx[i] = g * selu_slope(y[i]);
+        const size_t r = i / (size_t)cols;
+        const int c = (int)(i - r * (size_t)cols);
+        const T g = dy_b ? dy[r * ld_dy + c] + dy_b[r * ld_b + c] : dy[r * ld_dy + c];
+        dx[r * ld_dx + c] = g * selu_slope(y[r * ld_y + c]);
+    }
+}
+// dst[r][0..cols) = src[r][0..cols) with independent row strides (column blocks of the concat buffer <-> dense)
+template <typename T>
+__global__ __launch_bounds__(256) void copy_cols_kernel(const T *src, T *dst, size_t rows, int cols, int ld_s, int ld_d)
+{
+    const size_t n = rows * (size_t)cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (size_t)cols;
+        const int c = (int)(i - r * (size_t)cols);
+        dst[r * ld_d + c] = src[r * ld_s + c];
     }
 }
 

@@ -12,9 +12,12 @@ forward() keeps the activations; backward() takes dL/d(activation) of every laye
 consumer (the concat for classification, the logits for segmentation) and returns dL/dinput and the weight
 gradients, written into ONE fused buffer so that data-parallel training needs a single all-reduce.
 """
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _lib
 from . import conv3p_op as op
 from . import synth
 
@@ -25,11 +28,19 @@ HIDDEN = 9
 
 class Conv3pStack:
     def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234,
-                 use_cache=True, overlap_search=True, fuse_selu=True):
+                 use_cache=True, overlap_search=True, fuse_selu=True, c_stack=True):
         """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers).
         use_cache: keep the geometry (sorted points, populations, neighbour lists) of each layer's stencil in
-        a NeighborCache so that the search runs once per (points, stride) instead of once per op call."""
+        a NeighborCache so that the search runs once per (points, stride) instead of once per op call.
+        c_stack: drive a pass with ONE call of the stack-level C entry points (conv3p_stack_forward / _backward /
+        _prefetch, include/conv3p.h): one host crossing per pass, activations written straight into the concat
+        buffer.  Needs use_cache and fuse_selu; shapes outside the register-resident list fall back to the op-by-op
+        composition below (same results)."""
         self.use_cache = use_cache
+        self.c_stack = c_stack and use_cache and fuse_selu
+        self._inflight = None          # cache index of the batch between forward() and backward()
+        self._pending = {}             # cache index -> points tensor whose geometry was prefetched into it
+        self._scratch = None
         # SELU fused into the op's epilogues (conv3p_layer_*): 1 activation launch per step instead of 8
         self.fuse_selu = fuse_selu and use_cache
         # prefetch(): one search launch for all layers (conv3p_cache_prepare_multi_*) instead of one per layer.
@@ -66,6 +77,123 @@ class Conv3pStack:
             self.grad_views.append(self.fused_grad[o:o + n].view(f.shape))
             o += n
         self._saved = None
+        # description + pointer tables of the stack-level C entry points
+        self._desc = _lib.StackDesc()
+        self._desc.n_hidden = 4
+        self._desc.in_channels = in_channels
+        self._desc.hidden = HIDDEN
+        self._desc.num_class = int(num_class) if num_class is not None else 0
+        self._desc.fz = self._desc.fy = self._desc.fx = 3
+        for li, (_, _, s) in enumerate(self.layers):
+            for a in range(3):
+                self._desc.strides[li][a] = s
+        nl = len(self.layers)
+        self._fptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in self.filters])
+        self._gptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in self.grad_views])
+
+    # ------------------------------------------------------------------ stack-level C entry points
+    def _c_call(self, name, *args):
+        lib = _lib.load()
+        sfx = "f32" if self.dtype == torch.float32 else "f64"
+        rc = getattr(lib, "conv3p_stack_%s_%s" % (name, sfx))(ctypes.byref(self._desc), *args)
+        if rc == _lib.ERR_UNSUPPORTED:
+            return False
+        if rc != _lib.OK:
+            raise op.Conv3pRuntimeError("conv3p_stack_%s: %s (status %d)" % (name, _lib.status_string(rc), rc))
+        return True
+
+    def _real(self, v):
+        return ctypes.c_float(v) if self.dtype == torch.float32 else ctypes.c_double(v)
+
+    def _free_cache_index(self):
+        """A cache that neither serves the batch between forward() and backward() nor holds a pending prefetch."""
+        for idx in (1 - self._which, self._which):
+            if idx != self._inflight and idx not in self._pending:
+                return idx
+        raise op.Conv3pRuntimeError("prefetch(): both neighbour caches are busy (one batch in flight, one prefetch "
+                                    "pending) -- call forward() on the prefetched batch first")
+
+    def _c_prefetch(self, points):
+        for idx, t in self._pending.items():
+            if t is points:
+                return True
+        idx = self._free_cache_index()
+        cache = self._cache_slot(idx, points)
+        main = torch.cuda.current_stream(points.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=points.device)
+        B, N = points.shape[0], points.shape[1]
+        with torch.cuda.device(points.device):
+            ok = self._c_call("prefetch", points.data_ptr(), self._real(VOXEL), B, N, cache.buf.data_ptr(), cache.nbytes,
+                              cache.cfg_ptr(False), self._side.cuda_stream, main.cuda_stream)
+        if ok:
+            self._pending[idx] = points
+        return ok
+
+    def _c_forward(self, points, features):
+        B, N = points.shape[0], points.shape[1]
+        idx = None
+        for i, t in self._pending.items():
+            if t is points:
+                idx = i
+        if idx is None:
+            idx = self._which if self._which not in self._pending else 1 - self._which
+            self._pending.pop(idx, None)       # (a prefetch that was never consumed is simply overwritten)
+        cache = self._cache_slot(idx, points)
+        concat = torch.empty((B, N, HIDDEN * 4), dtype=self.dtype, device=points.device)
+        head = torch.empty((B, N, self.num_class), dtype=self.dtype, device=points.device) if self.num_class else None
+        main = torch.cuda.current_stream(points.device)
+        side = None
+        if self.overlap_search and idx not in self._pending:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=points.device)
+            side = self._side.cuda_stream
+        with torch.cuda.device(points.device):
+            ok = self._c_call("forward", points.data_ptr(), features.data_ptr(), ctypes.cast(self._fptrs, ctypes.c_void_p),
+                              self._real(VOXEL), B, N, concat.data_ptr(), head.data_ptr() if head is not None else None,
+                              cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(False), main.cuda_stream, side)
+        if not ok:
+            return None
+        self._pending.pop(idx, None)
+        self._which = idx
+        self._inflight = idx
+        self._cache = cache
+        acts = [concat[:, :, HIDDEN * i:HIDDEN * (i + 1)] for i in range(4)]
+        if head is not None:
+            acts.append(head)
+        self._saved = (points, features, acts, concat)
+        return acts
+
+    def _c_backward(self, upstream):
+        points, features, acts, concat = self._saved
+        B, N = points.shape[0], points.shape[1]
+        lib = _lib.load()
+        esz = 4 if self.dtype == torch.float32 else 8
+        need = lib.conv3p_stack_scratch_bytes(ctypes.byref(self._desc), esz, B, N)
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=points.device)
+        if self.num_class:
+            gconcat, ghead = None, upstream[0] if isinstance(upstream, (list, tuple)) else upstream
+            ghead = ghead.contiguous()
+        else:
+            ghead = None
+            gconcat = torch.cat(list(upstream), dim=2) if isinstance(upstream, (list, tuple)) else upstream
+            gconcat = gconcat.contiguous()
+        dx = torch.empty_like(features)
+        cache = self._cache
+        with torch.cuda.device(points.device):
+            ok = self._c_call("backward", points.data_ptr(), features.data_ptr(),
+                              ctypes.cast(self._fptrs, ctypes.c_void_p), self._real(VOXEL), B, N, concat.data_ptr(),
+                              acts[4].data_ptr() if self.num_class else None,
+                              gconcat.data_ptr() if gconcat is not None else None,
+                              ghead.data_ptr() if ghead is not None else None, dx.data_ptr(),
+                              ctypes.cast(self._gptrs, ctypes.c_void_p), self._scratch.data_ptr(), self._scratch.numel(),
+                              cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(True),
+                              torch.cuda.current_stream(points.device).cuda_stream)
+        self._inflight = None
+        if not ok:
+            raise op.Conv3pRuntimeError("conv3p_stack_backward: unsupported after a supported forward")
+        return dx, self.fused_grad
 
     def _cache_slot(self, idx, points):
         B, N = points.shape[0], points.shape[1]
@@ -100,6 +228,11 @@ class Conv3pStack:
         between prefetch() and the forward() that consumes it (that forward trusts the prefetch)."""
         if not self.use_cache:
             return
+        if self.c_stack:
+            points = points.contiguous()
+            if self._c_prefetch(points):
+                return
+            self.c_stack = False           # shapes the stack-level entry points do not take: op-by-op from now on
         # the cache that holds no pending prefetch: normally the one the current batch is NOT using; when
         # prefetch() is called before forward() of the batch prefetched earlier (i.e. the batch in `_which` is
         # finished: its backward has been enqueued), that finished batch's cache
@@ -144,6 +277,12 @@ class Conv3pStack:
         return main, events
 
     def forward(self, points, features):
+        if self.c_stack:
+            acts = self._c_forward(points.contiguous() if not points.is_contiguous() else points,
+                                   features.contiguous() if not features.is_contiguous() else features)
+            if acts is not None:
+                return acts
+            self.c_stack = False
         pf = self._prefetched
         p2 = getattr(self, "_pending2", None)
         if p2 is not None and p2[0] is points and self.use_cache:
@@ -184,6 +323,8 @@ class Conv3pStack:
     def backward(self, upstream):
         """upstream: classification -> list of 4 tensors dL/d(act_l) (the slices of dL/dconcat);
         segmentation -> [dL/dlogits_act].  Returns (dL/dfeatures, fused weight-gradient buffer)."""
+        if self.c_stack:
+            return self._c_backward(upstream)
         points, features, acts, concat = self._saved
         cache = self._cache if self.use_cache else None
         if self.num_class is not None:
@@ -191,6 +332,8 @@ class Conv3pStack:
             dconcat, _ = op.conv3p_grad(g, points, concat, self.filters[4], (1, 1, 1), VOXEL,
                                         grad_filter_out=self.grad_views[4], cache=cache, points_unchanged=True)
             ext = [dconcat[:, :, HIDDEN * i:HIDDEN * (i + 1)].contiguous() for i in range(4)]
+        elif isinstance(upstream, torch.Tensor):     # dL/dconcat as one (B, N, 36) tensor
+            ext = [upstream[:, :, HIDDEN * i:HIDDEN * (i + 1)].contiguous() for i in range(4)]
         else:
             ext = list(upstream)
         if self.fuse_selu:
