@@ -464,21 +464,31 @@ int zero_async(void *p, size_t bytes, hipStream_t s)
 }
 
 // ----------------------------------------------------------------------------- deep-channel path
-// (Cin, Cout) pairs served by the matrix-core kernels of conv3p_deep.hpp (fp32 only).
-#define CONV3P_DEEP_SHAPES(X) X(128, 256) X(32, 64) X(64, 64) X(64, 128) X(128, 128)
+// Channel shapes served by the matrix-core kernels of conv3p_deep.hpp (fp32 only): every layer with up to 128
+// channels on either side, padded to the instantiated sizes {32, 64, 128}, plus the 128 -> 256 layer of BASELINE
+// config 5.  (Cin, Cout) below are the PADDED sizes.
+#define CONV3P_DEEP_SHAPES(X) X(128, 256) X(32, 32) X(32, 64) X(32, 128) X(64, 32) X(64, 64) X(64, 128) X(128, 32) X(128, 64) X(128, 128)
 
+inline int deep_pad(int c) { return c <= 32 ? 32 : c <= 64 ? 64 : c <= 128 ? 128 : c <= 256 ? 256 : 0; }
+// padded (Cin, Cout) of a layer the deep path takes, or false
+inline bool deep_class(int elem, int cin, int cout, int &cip, int &cop)
+{
+    if (elem != 4 || cin < 1 || cout < 1) return false;
+    cip = deep_pad(cin);
+    cop = deep_pad(cout);
+    if (cip == 0 || cop == 0) return false;
+    if (cop == 256) return cin == 128 && cout == 256;     // only the exact cfg5 layer at 256
+    return cip <= 128;
+}
 inline bool deep_shape(int elem, int cin, int cout)
 {
-    if (elem != 4) return false;
-#define X(ci, co) if (cin == ci && cout == co) return true;
-    CONV3P_DEEP_SHAPES(X)
-#undef X
-    return false;
+    int a, b;
+    return deep_class(elem, cin, cout, a, b);
 }
 
 constexpr int kDwItems = 1024;        // target number of deep_dw_kernel work items (2 rounds at 2 per CU)
 struct DeepScratch {   // carved from the per-call scratch region
-    float *wt;             // filter transposed [F][Cout][Cin]
+    float *wt;             // zero-padded (and, for grad_input, transposed) filter [F][Kpad][Npad]
     uint2 *tap_meta;       // per pair slot, tap-major inside a tile: {neighbour, centre lane | population << 8}
     uint32_t *tap_off;     // [tiles][F+1]
     uint8_t *tile_flag;    // [tiles]
@@ -498,7 +508,8 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     char *p = static_cast<char *>(base);
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
-    s.wt = reinterpret_cast<float *>(take(nw * 4));
+    const size_t cip = (size_t)deep_pad(d.Cin), cop = (size_t)deep_pad(d.Cout);
+    s.wt = reinterpret_cast<float *>(take((size_t)d.ntap * cip * cop * 4));
     s.tap_meta = reinterpret_cast<uint2 *>(take(pair_slots * 8));
     s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
@@ -507,7 +518,7 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     s.tap_total = reinterpret_cast<uint32_t *>(take(65 * 4));
     s.tap_rng = reinterpret_cast<uint2 *>(take(64 * 8));
     s.items = reinterpret_cast<uint4 *>(take((size_t)(kDwItems + 64) * 16));
-    s.partials = reinterpret_cast<float *>(take((size_t)(kDwItems + 64) * d.Cin * d.Cout * 4 + nw * 4));
+    s.partials = reinterpret_cast<float *>(take((size_t)(kDwItems + 64) * cip * cop * 4 + nw * 4));
     s.bytes = off;
     return s;
 }
@@ -533,7 +544,8 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
 }
 
 template <int KD, int ND, bool BWD>
-int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, float *out, const DeepScratch &ds)
+int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, float *out, const DeepScratch &ds,
+                     int kreal, int nreal)
 {
     const Dims &d = c.d;
     const auto &S = c.L.slot[c.slot];
@@ -546,16 +558,32 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((deep_gemm_kernel<KD, ND, BWD>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs,
                        S.segs, src, Bm, d.N, d.ntiles, d.ntap, ds.sched, ds.sched_cap, out, ds.tap_meta, ds.tap_off,
-                       ds.tile_flag);
+                       ds.tile_flag, kreal, nreal);
     return hip_ok();
 }
 
+int launch_pad_filter(const Call<float> &c, const float *filter, int kp, int np, int transpose, float *wp)
+{
+    const size_t n = (size_t)c.d.ntap * kp * np;
+    Scope sc(K_TRANSPOSE, c.s);
+    hipLaunchKernelGGL(pad_filter_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0,
+                       c.s, filter, c.d.ntap, c.d.Cin, c.d.Cout, kp, np, transpose, wp);
+    return hip_ok();
+}
+
+// CI, CO: the padded instantiation; c.d.Cin / c.d.Cout: the layer's real channel counts
 template <int CI, int CO>
 int deep_forward(const Call<float> &c, const float *input, const float *filter, float *output)
 {
-    const DeepScratch ds = carve_deep(c.d, (size_t)c.d.B * c.L.pairs_per_cloud, c.L.partials);
+    const Dims &d = c.d;
+    const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials);
     TRY(launch_deep_order<false>(c, ds));
-    TRY((launch_deep_gemm<CI, CO, false>(c, input, filter, output, ds)));
+    const float *Bm = filter;
+    if (d.Cin != CI || d.Cout != CO) {
+        TRY(launch_pad_filter(c, filter, CI, CO, 0, ds.wt));
+        Bm = ds.wt;
+    }
+    TRY((launch_deep_gemm<CI, CO, false>(c, input, Bm, output, ds, d.Cin, d.Cout)));
     // tiles the deep kernels could not take (pair buffer overflow, non-finite rows): generic kernel, flagged tiles
     return launch_forward<float, 0, 0>(c, input, filter, output, ds.tile_flag);
 }
@@ -566,17 +594,12 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
 {
     const Dims &d = c.d;
     const auto &S = c.L.slot[c.slot];
-    const size_t nw = (size_t)d.ntap * CI * CO;
+    const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
     const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials);
     TRY(launch_deep_order<true>(c, ds));
-    {
-        Scope sc(K_TRANSPOSE, c.s);
-        hipLaunchKernelGGL(transpose_filter_kernel, dim3((unsigned)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024)),
-                           dim3(256), 0, c.s, filter, d.ntap, CI, CO, ds.wt);
-    }
-    TRY(hip_ok());
+    TRY(launch_pad_filter(c, filter, CO, CI, 1, ds.wt));
     // dX = sum_f' G_f' . W[f']^T  (K = Cout, N = Cin)
-    TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds)));
+    TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds, d.Cout, d.Cin)));
     {
         const size_t lds = a16((size_t)65 * (CI + 1) * 4) + a16((size_t)kDeepBlk * (CO + 32) * 4) +
                            3 * (size_t)kDeepBatch * 4 + 256 + ((CONV3P_ABLATE & 8388608) ? 20000 : 0);
@@ -586,7 +609,7 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(kDwItems + 64), dim3(256), lds, c.s, c.L.pts, S.pairs, S.segs,
                            ds.tap_meta, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap, ds.tile_flag, ds.items,
-                           ds.tap_total + 64, ds.partials);
+                           ds.tap_total + 64, ds.partials, d.Cin, d.Cout);
     }
     TRY(hip_ok());
     // flagged tiles: generic kernel adds into the zeroed rows / into its own grad_filter-shaped buffer
@@ -595,8 +618,8 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
     TRY((launch_backward<float, 0, 0>(c, grad_out, input, filter, grad_input, extra, ds.tile_flag)));
     {
         Scope sc(K_REDUCE, c.s);
-        hipLaunchKernelGGL(deep_reduce_kernel, dim3((unsigned)((CI * CO + 255) / 256), (unsigned)d.ntap), dim3(256), 0, c.s,
-                           ds.partials, ds.tap_rng, extra, CI * CO, grad_filter);
+        hipLaunchKernelGGL(deep_reduce_kernel, dim3((unsigned)((d.Cin * d.Cout + 255) / 256), (unsigned)d.ntap), dim3(256), 0,
+                           c.s, ds.partials, ds.tap_rng, extra, CI * CO, CO, d.Cin, d.Cout, grad_filter);
     }
     return hip_ok();
 }
@@ -698,6 +721,13 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     return CONV3P_OK;
 }
 
+// Stack-level backward: a layer's grad_filter partials stay in the caller's region and are reduced later, together
+// with the other layers', by one reduce_multi_kernel launch.
+template <typename T> struct DeferredReduce {
+    T *region = nullptr;      // in: where this layer's partials go (>= reduce_region_bytes)
+    ReduceJob<T> job{};       // out: what to reduce (nslots == 0: the layer reduced its grad_filter itself)
+};
+
 template <typename T> int selu_impl(const T *x, T *y, size_t n, void *stream);
 // rows x cols values; lds = {ld_y, ld_dy, ld_b, ld_dx} or nullptr for dense operands
 template <typename T>
@@ -732,9 +762,10 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
 #undef X
     if (c.strided) return CONV3P_ERR_UNSUPPORTED;   // (a register-path shape whose LDS did not fit)
     if constexpr (sizeof(T) == 4) {
-        if (c.L.ngroups == 1 && c.deep_scratch_ok) {
+        int cip = 0, cop = 0;
+        if (c.L.ngroups == 1 && c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {
 #define X(ci, co)                                                                                    \
-    if (Cin == ci && Cout == co) {                                                                   \
+    if (cip == ci && cop == co) {                                                                    \
         int rc = deep_forward<ci, co>(c, input, filter, output);                                     \
         if (rc != CONV3P_ERR_UNSUPPORTED) return rc != CONV3P_OK || !act ? rc : selu_impl<T>(output, output, out_elems, stream); \
     }
@@ -821,7 +852,7 @@ template <typename T>
 int backward_impl(const T *grad_out, const T *points, const T *input, const T *filter,
                   const int32_t *stride, T voxel, int B, int N, int Cin, int Cout, int fz, int fy, int fx,
                   T *grad_input, T *grad_filter, const Where &wh, void *stream, bool act = false,
-                  const T *addend = nullptr, const RowLd *ldp = nullptr)
+                  const T *addend = nullptr, const RowLd *ldp = nullptr, DeferredReduce<T> *defer = nullptr)
 {
     Dims d{B, N, Cin, Cout, fz, fy, fx, 0, 0};
     TRY(check(d, stride, (double)voxel, true));
@@ -851,14 +882,20 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     int rc = CONV3P_ERR_UNSUPPORTED;
     int nslots = (int)grid_of(make_blockmap(d));
+    T *region = defer ? defer->region : nullptr;
 #define X(ci, co)                                                                                    \
-    if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input);
+    if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input, region);
     CONV3P_SMALL_SHAPES(X)
 #undef X
+    if (defer && rc == CONV3P_OK) {
+        defer->job = ReduceJob<T>{region, grad_filter, nslots, (unsigned)nw};
+        return CONV3P_OK;
+    }
     if constexpr (sizeof(T) == 4) {
-        if (rc == CONV3P_ERR_UNSUPPORTED && c.L.ngroups == 1 && c.deep_scratch_ok) {
+        int cip = 0, cop = 0;
+        if (rc == CONV3P_ERR_UNSUPPORTED && c.L.ngroups == 1 && c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {
 #define X(ci, co)                                                                                    \
-    if (Cin == ci && Cout == co) {                                                                   \
+    if (cip == ci && cop == co) {                                                                    \
         int drc = deep_backward<ci, co>(c, grad_out, input, filter, grad_input, grad_filter);        \
         if (drc != CONV3P_ERR_UNSUPPORTED)                                                           \
             return drc != CONV3P_OK || !act ? drc                                                    \
@@ -953,7 +990,7 @@ size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, in
     CONV3P_SMALL_SHAPES(X)
 #undef X
 #define X(ci, co)                                                                                    \
-    if (elem == 4 && ci <= max_Cin && co <= max_Cout) {                                              \
+    if (elem == 4 && max_Cin > 0 && max_Cout > 0 && ci <= deep_pad(max_Cin) && co <= deep_pad(max_Cout)) { \
         Dims dd{B, N, ci, co, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};                    \
         const size_t need = deep_scratch_bytes(dd, (size_t)B * N * (size_t)ppp);                     \
         if (need > b) b = need;                                                                      \
@@ -1045,11 +1082,12 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
     hipStream_t main = static_cast<hipStream_t>(stream);
     // geometry: already enqueued by conv3p_stack_prefetch_* for these points, or enqueued now on the side stream
     // (each layer's search then runs while the previous layers accumulate), or built inline by the op calls
-    bool events = false;
+    bool events = false, prefetched = false;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         auto it = g_caches.find(cache);
-        if (it != g_caches.end() && it->second.pending_points == points && it->second.pending_layers == nl) events = true;
+        if (it != g_caches.end() && it->second.pending_points == points && it->second.pending_layers == nl)
+            events = prefetched = true;
         if (it != g_caches.end()) it->second.pending_points = nullptr;
     }
     if (!events && side_stream != nullptr && side_stream != stream) {
@@ -1063,8 +1101,11 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
         std::lock_guard<std::mutex> lk(g_cache_mu);
         ev = g_caches[cache].ready;
     }
+    // prefetched geometry (normally finished long ago, under the previous batch's backward): ONE wait on the last
+    // layer's event covers them all; geometry enqueued just now: per-layer waits, so that layer 0 starts early
+    if (prefetched && hipStreamWaitEvent(main, ev[nl - 1], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
     for (int l = 0; l < nl; ++l) {
-        if (events && hipStreamWaitEvent(main, ev[l], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
+        if (events && !prefetched && hipStreamWaitEvent(main, ev[l], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
         conv3p_cache_config c2 = *cfg;
         c2.flags = (l > 0 || events) ? CONV3P_CACHE_POINTS_UNCHANGED : 0;   // the first call of a step re-validates
         const bool head = l == sd->n_hidden;
@@ -1082,12 +1123,24 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
     return CONV3P_OK;
 }
 
+// bytes of layer l's grad_filter partials (one per backward workgroup)
+template <typename T> size_t stack_region_bytes(const conv3p_stack_desc *sd, int l, int B, int N)
+{
+    const bool head = l == sd->n_hidden;
+    const int Cin = head ? sd->n_hidden * sd->hidden : (l == 0 ? sd->in_channels : sd->hidden);
+    const int Cout = head ? sd->num_class : sd->hidden;
+    Dims d{B, N, Cin, Cout, sd->fz, sd->fy, sd->fx, sd->fz * sd->fy * sd->fx, (N + kTile - 1) / kTile};
+    return up((size_t)d.ntap * Cin * Cout * (size_t)grid_of(make_blockmap(d)) * sizeof(T));
+}
+
 template <typename T> size_t stack_scratch_bytes(const conv3p_stack_desc *sd, int B, int N)
 {
     const size_t rows = (size_t)B * N;
     const size_t wide = (size_t)(sd->hidden > sd->num_class ? sd->hidden : sd->num_class);
-    // two ping-pong gradient buffers + the head's gradient w.r.t. the concat
-    return up(rows * wide * sizeof(T)) * 2 + up(rows * (size_t)sd->n_hidden * sd->hidden * sizeof(T));
+    // two ping-pong gradient buffers + the head's gradient w.r.t. the concat + every layer's grad_filter partials
+    size_t b = up(rows * wide * sizeof(T)) * 2 + up(rows * (size_t)sd->n_hidden * sd->hidden * sizeof(T));
+    for (int l = 0; l < stack_layers(sd); ++l) b += stack_region_bytes<T>(sd, l, B, N);
+    return b;
 }
 
 template <typename T>
@@ -1110,6 +1163,32 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
     T *ga = reinterpret_cast<T *>(sp);
     T *gb = reinterpret_cast<T *>(sp + up(rows * wide * sizeof(T)));
     T *dconcat = reinterpret_cast<T *>(sp + 2 * up(rows * wide * sizeof(T)));
+    // every layer leaves its grad_filter partials in its own region; ONE launch reduces them all at the end, so the
+    // chain of dependent backward kernels is not interleaved with reductions
+    DeferredReduce<T> red[CONV3P_STACK_MAX_LAYERS + 1];
+    {
+        char *rp = sp + 2 * up(rows * wide * sizeof(T)) + up(rows * (size_t)CW * sizeof(T));
+        for (int l = 0; l < stack_layers(sd); ++l) {
+            red[l].region = reinterpret_cast<T *>(rp);
+            rp += stack_region_bytes<T>(sd, l, B, N);
+        }
+    }
+    auto reduce_all = [&]() -> int {
+        ReduceJobs<T> jobs{};
+        int nj = 0;
+        unsigned gx = 0;
+        for (int l = 0; l < stack_layers(sd); ++l)
+            if (red[l].job.nslots > 0) {
+                jobs.job[nj++] = red[l].job;
+                const unsigned g = (red[l].job.nw + 63u) / 64u;
+                gx = g > gx ? g : gx;
+            }
+        if (nj == 0) return CONV3P_OK;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        Scope sc(K_REDUCE, s);
+        hipLaunchKernelGGL(reduce_multi_kernel<T>, dim3(gx, (unsigned)nj), dim3(1024), 0, s, jobs);
+        return hip_ok();
+    };
     auto where = [&]() {
         return persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
                           cfg->max_Cin, cfg->max_Cout, CONV3P_CACHE_POINTS_UNCHANGED);
@@ -1121,7 +1200,8 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
         // g = dL/d(head conv output) = grad_head * selu'(head_out)
         TRY(selu_grad_impl<T>(head_out, grad_head, nullptr, ga, rows, sd->num_class, nullptr, stream));
         TRY(backward_impl<T>(ga, points, concat, filters[nh], sd->strides[nh], voxel, B, N, CW, sd->num_class, sd->fz,
-                             sd->fy, sd->fx, dconcat, grad_filters[nh], where(), stream));
+                             sd->fy, sd->fx, dconcat, grad_filters[nh], where(), stream, false, nullptr, nullptr,
+                             &red[nh]));
         if (grad_concat) {   // both consumers: dconcat += grad_concat  (slope 1: reuse the fused add with y = +1 ...)
             return CONV3P_ERR_UNSUPPORTED;   // not needed by either model; keep the contract honest
         }
@@ -1139,11 +1219,12 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
         const int Cin = H;
         TRY(backward_impl<T>(g, points, concat + (size_t)H * (l - 1), filters[l], sd->strides[l], voxel, B, N, Cin, H,
                              sd->fz, sd->fy, sd->fx, gn, grad_filters[l], where(), stream, /*act=*/true,
-                             ext + (size_t)H * (l - 1), &ld));
+                             ext + (size_t)H * (l - 1), &ld, &red[l]));
         T *t = g; g = gn; gn = t;
     }
-    return backward_impl<T>(g, points, input, filters[0], sd->strides[0], voxel, B, N, sd->in_channels, H, sd->fz, sd->fy,
-                            sd->fx, grad_input, grad_filters[0], where(), stream);
+    TRY(backward_impl<T>(g, points, input, filters[0], sd->strides[0], voxel, B, N, sd->in_channels, H, sd->fz, sd->fy,
+                         sd->fx, grad_input, grad_filters[0], where(), stream, false, nullptr, nullptr, &red[0]));
+    return reduce_all();
 }
 
 bool cache_cfg_ok(const conv3p_cache_config *cfg)

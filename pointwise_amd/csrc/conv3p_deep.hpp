@@ -16,6 +16,10 @@
 //   * dW[f'] = X_tile^T . (dY rows / count) needs no per-centre reduction at all: the pair index is the GEMM's
 //     k dimension.
 // Taps with no neighbour in the tile are skipped.
+// Channel counts: the kernels are instantiated for KDIM, NDIM in {32, 64, 128} (+ the 128 -> 256 layer) and take the
+// REAL row lengths at run time: rows are read / written with their real length and stride, columns past the real
+// count are zero in LDS, and the filter operand is a zero-padded copy [F][KDIM][NDIM] (pad_filter_kernel).  Any
+// fp32 layer with up to 128 channels on either side therefore runs here, deterministically.
 //
 // Fragment layouts of mfma_f32_32x32x2f32 (cdna_hip_programming.md section 3):
 //   A operand: lane l holds A[i = l & 31][k = l >> 5];  B operand: lane l holds B[k = l >> 5][j = l & 31];
@@ -34,6 +38,22 @@
 namespace conv3p {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 4 consecutive floats of a row of `len` values starting at column `col` (zeros past the end); rows are only
+// dword-aligned in general (global_load_dwordx4 needs no more on gfx950)
+__device__ __forceinline__ float4 load_row4(const float *__restrict__ row, int col, int len)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col + 4 <= len) {
+        const float4_a4 t = *reinterpret_cast<const float4_a4 *>(row + col);
+        v = make_float4(t.x, t.y, t.z, t.w);
+    } else if (col < len) {
+        v.x = row[col];
+        if (col + 1 < len) v.y = row[col + 1];
+        if (col + 2 < len) v.z = row[col + 2];
+    }
+    return v;
+}
 
 constexpr int kDeepBlk = 32;      // records per staged block (= 16 MFMA k-steps)
 constexpr int kDeepBatch = 256;   // records whose metadata is fetched at once
@@ -248,7 +268,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                                                         float *__restrict__ out,
                                                         const uint2 *__restrict__ tap_meta,
                                                         const uint32_t *__restrict__ tap_off,
-                                                        uint8_t *__restrict__ tile_flag)
+                                                        uint8_t *__restrict__ tile_flag,
+                                                        int kreal, int nreal)   // real row lengths of src / out
 {
     constexpr int LDA = KDIM + 1;
     constexpr int LDR = KDIM + 32;                        // half-waves read different rows: 32 banks apart
@@ -285,20 +306,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     const size_t tile_id = (size_t)b * ntiles + qt;
     const uint2 tseg = segs[tile_id];
     if (wave == 0) qorig[lane] = pts[tile_id * kTile + lane].idx;
-    float *out_cloud = out + (size_t)b * N * NDIM;
+    float *out_cloud = out + (size_t)b * N * nreal;
     if (tseg.y == kSegOverflow) {
         // the cloud's pair region overflowed: leave zero rows; the generic kernel is launched afterwards for the
         // tiles deep_order_kernel flagged (it can search the tile itself)
         __syncthreads();
         for (int e = threadIdx.x; e < 64 * NDIM; e += 256) {
             const int orig = qorig[e / NDIM];
-            if (orig >= 0) out_cloud[(size_t)orig * NDIM + (e % NDIM)] = 0.0f;
+            if (orig >= 0 && (e % NDIM) < nreal) out_cloud[(size_t)orig * nreal + (e % NDIM)] = 0.0f;
         }
         return;
     }
     const uint2 *meta = tap_meta + tseg.x;
     const uint32_t *toff = tap_off + tile_id * (size_t)(ntap + 1);
-    const float *src_cloud = src + (size_t)b * N * KDIM;
+    const float *src_cloud = src + (size_t)b * N * kreal;
 
     f32x16 acc[OPW];
 #pragma unroll
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             const int e = (int)threadIdx.x + 256 * u;
             const uint32_t p = p0 + (uint32_t)(e / F4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < nrec) v = *reinterpret_cast<const float4 *>(src_cloud + (size_t)mcand[p] * KDIM + 4 * (e % F4));
+            if (p < nrec) v = load_row4(src_cloud + (size_t)mcand[p] * kreal, 4 * (e % F4), kreal);
             rv[u] = v;                                   // nothing here may consume v: the loads stay in flight
         }
     };
@@ -452,7 +473,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             for (int r = 0; r < 16; ++r) {
                 const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int orig = qorig[row];
-                if (orig >= 0) out_cloud[(size_t)orig * NDIM + (cb0 + 2 * j) * 32 + (lane & 31)] = bad ? 0.0f : acc[j][r];
+                const int col = (cb0 + 2 * j) * 32 + (lane & 31);
+                if (orig >= 0 && col < nreal) out_cloud[(size_t)orig * nreal + col] = bad ? 0.0f : acc[j][r];
             }
     }
 }
@@ -602,14 +624,16 @@ __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restr
 }
 
 // grad_filter[f] = sum of tap f's item partials (ascending j: fixed order) + the generic kernel's contribution
+// (partial slots are [CINP][COUTP] of the padded instantiation; grad_filter and `extra` have the real layout)
 __global__ __launch_bounds__(256) void deep_reduce_kernel(const float *__restrict__ partials,
                                                           const uint2 *__restrict__ tap_rng,
-                                                          const float *__restrict__ extra, int per_tap,
-                                                          float *__restrict__ grad_filter)
+                                                          const float *__restrict__ extra, int per_tap, int coutp,
+                                                          int cin, int cout, float *__restrict__ grad_filter)
 {
     const int f = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= per_tap) return;
+    const int er = blockIdx.x * 256 + threadIdx.x;       // element of the real [cin][cout] block
+    if (er >= cin * cout) return;
+    const int e = (er / cout) * coutp + (er % cout);      // ... and of the padded one
     const uint2 rg = tap_rng[f];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     uint32_t j = 0;
@@ -620,7 +644,7 @@ __global__ __launch_bounds__(256) void deep_reduce_kernel(const float *__restric
         s3 += partials[(size_t)(rg.x + j + 3) * per_tap + e];
     }
     for (; j < rg.y; ++j) s0 += partials[(size_t)(rg.x + j) * per_tap + e];
-    grad_filter[(size_t)f * per_tap + e] = ((s0 + s1) + (s2 + s3)) + extra[(size_t)f * per_tap + e];
+    grad_filter[(size_t)f * cin * cout + er] = ((s0 + s1) + (s2 + s3)) + extra[(size_t)f * cin * cout + er];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -638,7 +662,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     const PointRec<float> *__restrict__ pts, const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs,
     const uint2 *__restrict__ tap_meta, const uint32_t *__restrict__ tap_off, const float *__restrict__ grad_out,
     const float *__restrict__ input, int B, int N, int ntiles, int ntap, const uint8_t *__restrict__ tile_flag,
-    const uint4 *__restrict__ items, const uint32_t *__restrict__ nitems, float *__restrict__ partials)
+    const uint4 *__restrict__ items, const uint32_t *__restrict__ nitems, float *__restrict__ partials,
+    int cin, int cout)   // real channel counts (<= CIN, COUT); the partial slots are [CIN][COUT]
 {
     constexpr int LDX = CIN + 1;
     constexpr int LDR = COUT + 32;
@@ -689,7 +714,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         const int b = (int)(tile / ntiles);
         const uint2 tseg = segs[tile];
         const uint2 *meta = tap_meta + tseg.x;
-        const float *dy_cloud = grad_out + (size_t)b * N * COUT;
+        const float *dy_cloud = grad_out + (size_t)b * N * cout;
         DBG_T(0)
         __syncthreads();                                    // previous tile's X / rows consumed
         if (wave == 0) qorig[lane] = pts[tile * kTile + lane].idx;
@@ -706,7 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
                 const int orig = qorig[e / (CIN / 4)];
                 xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (orig >= 0 && !(CONV3P_ABLATE & 2097152))
-                    xv[u] = *reinterpret_cast<const float4 *>(input + ((size_t)b * N + orig) * CIN + 4 * (e % (CIN / 4)));
+                    xv[u] = load_row4(input + ((size_t)b * N + orig) * cin, 4 * (e % (CIN / 4)), cin);
             }
 #pragma unroll
             for (int u = 0; u < XPT; ++u) {
@@ -721,7 +746,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
                 const int e = (int)threadIdx.x + 256 * u;
                 const uint32_t p = p0 + (uint32_t)(e / F4);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // rows past the last record contribute nothing
-                if (p < nrec) v = *reinterpret_cast<const float4 *>(dy_cloud + (size_t)mcand[p] * COUT + 4 * (e % F4));
+                if (p < nrec) v = load_row4(dy_cloud + (size_t)mcand[p] * cout, 4 * (e % F4), cout);
                 rv[u] = v;                               // nothing here may consume v: the loads stay in flight
             }
         };
@@ -808,15 +833,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     }
 }
 
-// filter [F][Cin][Cout] -> [F][Cout][Cin]
-__global__ __launch_bounds__(256) void transpose_filter_kernel(const float *__restrict__ w, int ntap, int cin,
-                                                               int cout, float *__restrict__ wt)
+// filter [F][cin][cout] -> zero-padded B operand of deep_gemm_kernel:
+//   transpose == 0: [F][kp][np] with rows k < cin, columns n < cout             (forward:   out = M_f . W[f])
+//   transpose != 0: [F][kp][np] with rows k < cout, columns n < cin = W[f]^T    (grad_input: dX = G_f . W[f]^T)
+__global__ __launch_bounds__(256) void pad_filter_kernel(const float *__restrict__ w, int ntap, int cin, int cout,
+                                                         int kp, int np, int transpose, float *__restrict__ wp)
 {
-    const size_t n = (size_t)ntap * cin * cout;
+    const size_t n = (size_t)ntap * kp * np;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t f = e / ((size_t)cin * cout), r = e % ((size_t)cin * cout);
-        const size_t c = r / cin, k = r % cin;              // e indexes wt[f][c][k]
-        wt[e] = w[(f * cin + k) * cout + c];
+        const size_t f = e / ((size_t)kp * np), r = e % ((size_t)kp * np);
+        const int k = (int)(r / np), c = (int)(r % np);
+        float v = 0.0f;
+        if (!transpose) { if (k < cin && c < cout) v = w[(f * cin + k) * cout + c]; }
+        else if (k < cout && c < cin) v = w[(f * cin + c) * cout + k];
+        wp[e] = v;
     }
 }
 

@@ -1237,6 +1237,48 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const T *__restri
     }
 }
 
+// The same for several layers in ONE launch (blockIdx.y = layer): the stack-level backward leaves every layer's
+// partials in its own region and reduces them all at the end, off the chain of dependent backward kernels.
+constexpr int kMaxReduceJobs = 9;
+template <typename T> struct ReduceJob {
+    const T *partials;
+    T *grad_filter;
+    int nslots;
+    unsigned nw;
+};
+template <typename T> struct ReduceJobs {
+    ReduceJob<T> job[kMaxReduceJobs];
+};
+template <typename T>
+__global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceJobs<T> jobs)
+{
+    __shared__ T part[16][64];
+    const ReduceJob<T> &j = jobs.job[blockIdx.y];
+    if ((size_t)blockIdx.x * 64 >= j.nw) return;   // uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + lane, nw = j.nw;
+    const T *partials = j.partials;
+    T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+    if (e < nw) {
+        int p = wave;
+        for (; p + 48 < j.nslots; p += 64) {
+            s0 += partials[(size_t)p * nw + e];
+            s1 += partials[(size_t)(p + 16) * nw + e];
+            s2 += partials[(size_t)(p + 32) * nw + e];
+            s3 += partials[(size_t)(p + 48) * nw + e];
+        }
+        for (; p < j.nslots; p += 16) s0 += partials[(size_t)p * nw + e];
+    }
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && e < nw) {
+        T s = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) s += part[w][lane];
+        j.grad_filter[e] = s;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void selu_kernel(const T *x, T *y, size_t n)   // y may alias x
 {
