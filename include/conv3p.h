@@ -303,6 +303,25 @@ int conv3p_stack_backward_f64(const conv3p_stack_desc *desc, const double *point
                               double *grad_input, double *const *grad_filters, void *scratch, size_t scratch_bytes,
                               void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The providers' host pre-step on the device.  The reference prepares every batch with
+ * per-cloud numpy loops -- rotate_point_cloud + jitter_point_cloud (/root/reference/modelnet_provider.py:23-75) and
+ * sort_point_cloud_xyz / sort_point_cloud_xyz2 (/root/reference/util.py:55-109).  Random numbers stay the caller's.
+ *
+ * conv3p_augment_f32:  out[b,i,:] = (float)( clip(sigma * noise[b,i,:], +-clip) + (double)(float)(p[b,i,:] . R_b) ),
+ *   R_b the rotation about the up (y) axis by the angle whose {cos, sin} is cos_sin[b] (device, double[B][2]; NULL =
+ *   no rotation); noise (device, double (B,N,3), e.g. standard normal; NULL = no jitter).  out may alias in.
+ * conv3p_sort_xyz_order_f32:  order[b][r] = index of the point that comes r-th in cloud b sorted by x, then y,
+ *   then z (what util.py:66-68's three argsorts produce), remaining ties by original index.  data rows have
+ *   row_floats floats starting with x, y, z.  N <= 8192 (CONV3P_ERR_UNSUPPORTED beyond).
+ * conv3p_gather_rows:  dst[b][r] = src[b][order[b][r]] for rows of row_bytes bytes: applies one order to the
+ *   points and to every per-point attribute / label array (sort_point_cloud_xyz2).  dst must not alias src.
+ * ------------------------------------------------------------------------------------------- */
+int conv3p_augment_f32(const float *points_in, const double *cos_sin, const double *noise, double sigma, double clip,
+                       int B, int N, float *points_out, void *stream);
+int conv3p_sort_xyz_order_f32(const float *data, int B, int N, int row_floats, int32_t *order, void *stream);
+int conv3p_gather_rows(const void *src, const int32_t *order, int B, int N, int row_bytes, void *dst, void *stream);
+
 /* Kernel-level timing with HIP events recorded on the caller's stream (bench.py uses it
  * to derive the roofline of the dominant kernel).  Off by default; when enabled every
  * kernel launch of this library is bracketed by an event pair.  read() synchronises the

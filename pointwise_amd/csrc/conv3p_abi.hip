@@ -15,6 +15,7 @@
 // The stateless entry points run the same kernels on the caller's scratch with force = 1.
 #include "../../include/conv3p.h"
 #include "conv3p_kernels.hpp"
+#include "conv3p_prestep.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -265,7 +266,8 @@ size_t backward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPe
 {
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
     size_t deep = 0;
-    if (deep_shape(elem, d.Cin, d.Cout)) deep = deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+    if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
+        deep = deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     // register path: one partial per workgroup; generic path (also the fallback of the other two): generic_slots
     const size_t slots = small_shape(elem, d.Cin, d.Cout) ? (size_t)grid_of(make_blockmap(d)) : (size_t)generic_slots(d, elem);
     const size_t plain = nw * slots * (size_t)elem;
@@ -274,7 +276,8 @@ size_t backward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPe
 
 size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
 {
-    if (deep_shape(elem, d.Cin, d.Cout)) return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+    if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
+        return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     return 0;
 }
 
@@ -1447,6 +1450,49 @@ size_t conv3p_stack_scratch_bytes(const conv3p_stack_desc *desc, int elem_bytes,
     }
 STACK_ENTRY(f32, float)
 STACK_ENTRY(f64, double)
+
+int conv3p_augment_f32(const float *points_in, const double *cos_sin, const double *noise, double sigma, double clip,
+                       int B, int N, float *points_out, void *stream)
+{
+    if (B < 0 || N < 0 || !(clip > 0.0) || !(sigma >= 0.0)) return CONV3P_ERR_INVALID_ARGUMENT;   // assert(clip > 0), :72
+    const size_t total = (size_t)B * N;
+    if (total == 0) return CONV3P_OK;
+    if (!points_in || !points_out) return CONV3P_ERR_INVALID_ARGUMENT;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(augment_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), points_in,
+                       reinterpret_cast<const double2 *>(cos_sin), noise, sigma, clip, points_out, total, N);
+    return hip_ok();
+}
+
+int conv3p_sort_xyz_order_f32(const float *data, int B, int N, int row_floats, int32_t *order, void *stream)
+{
+    if (B < 0 || N < 0 || row_floats < 3) return CONV3P_ERR_INVALID_ARGUMENT;
+    if ((size_t)B * N == 0) return CONV3P_OK;
+    if (!data || !order) return CONV3P_ERR_INVALID_ARGUMENT;
+    if (N > 8192) return CONV3P_ERR_UNSUPPORTED;
+    int npad = 64;
+    while (npad < N) npad <<= 1;
+    const size_t lds = (size_t)npad * 16;
+    const int threads = npad / 2 < 1024 ? (npad / 2 < 64 ? 64 : npad / 2) : 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sort_xyz_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(sort_xyz_kernel, dim3((unsigned)B), dim3(threads), lds, static_cast<hipStream_t>(stream), data, N,
+                       row_floats, npad, order);
+    return hip_ok();
+}
+
+int conv3p_gather_rows(const void *src, const int32_t *order, int B, int N, int row_bytes, void *dst, void *stream)
+{
+    if (B < 0 || N < 0 || row_bytes < 1) return CONV3P_ERR_INVALID_ARGUMENT;
+    const size_t rows = (size_t)B * N;
+    if (rows == 0) return CONV3P_OK;
+    if (!src || !order || !dst || src == dst) return CONV3P_ERR_INVALID_ARGUMENT;
+    const size_t work = rows * (size_t)((row_bytes & 3) == 0 ? row_bytes >> 2 : row_bytes);
+    const unsigned grid = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const char *>(src), order, N, row_bytes, static_cast<char *>(dst), rows);
+    return hip_ok();
+}
 
 int conv3p_profile_enable(int on)
 {

@@ -15,7 +15,8 @@ from tests.parity_util import TOL, make_case, rel_err
 
 pytestmark = pytest.mark.gpu
 VOX = 0.1
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("prestep_"))
 
 
 @pytest.fixture(scope="module")

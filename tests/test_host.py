@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_load_binds_and_reports_version():
     lib = _lib.load()
-    assert lib.conv3p_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.conv3p_abi_version() == _lib.ABI_VERSION == 3
     assert _lib.status_string(0) == "ok"
     assert "workspace" in _lib.status_string(_lib.ERR_WORKSPACE)
     assert lib.conv3p_profile_kinds() >= 5
@@ -64,7 +64,7 @@ def test_cache_bytes():
     one = lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(1, 27, 0, 9, 9)))
     four = lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(cfg))
     assert 0 < one < four and four % 256 == 0
-    assert four >= 4 * 32 * 2048 * (27 * 4 + 256 * 16)              # populations + pair records per slot
+    assert four >= 4 * 32 * 2048 * (2 * 27 * 4 + 256 * 8)           # populations (two orders) + 8-byte pair records per slot
     assert lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(0, 27, 0, 9, 9))) == 0
     assert lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(4, 5000, 0, 9, 9))) == 0
     assert lib.conv3p_cache_bytes(2, 32, 2048, ctypes.byref(cfg)) == 0
