@@ -50,6 +50,57 @@ def _worker(rank, world, port, B, out_dir):
     dist.destroy_process_group()
 
 
+def _stack_worker(rank, world, port, B, out_dir):
+    """Each rank fills a real Conv3pStack's fused gradient buffer through its grad_views (the layout the stack-level
+    backward writes into) from its shard, then the one fused all-reduce; plus a cfg5-sized (884 736 floats) buffer."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import oracle
+    from pointwise_amd import distributed, stack, synth
+    distributed.init_from_env(backend="gloo")
+    st = stack.Conv3pStack(3, 13, device="cpu", dtype=torch.float64, seed=9)      # 5 layers incl. the 36 -> 13 head
+    assert st.fused_grad.numel() == sum(27 * ci * co for ci, co, _ in st.layers)
+    lo, hi = distributed.shard_bounds(B, world, rank)
+    P = synth.modelnet_like(B, 96, seed=70).astype(np.float64)
+    for li, (ci, co, s) in enumerate(st.layers):
+        X = synth.features(B, 96, ci, 71 + li, dtype=np.float64)
+        dY = synth.upstream_grad(B, 96, co, 81 + li, dtype=np.float64)
+        _, dw = oracle.backward(dY[lo:hi], P[lo:hi], X[lo:hi], st.filters[li].numpy(), (s, s, s), 0.1)
+        st.grad_views[li].copy_(torch.from_numpy(dw))          # what the backward kernels do on the device
+    distributed.allreduce_weight_grads(st.fused_grad)
+    big = torch.full((27 * 128 * 256,), float(rank + 1), dtype=torch.float32)   # cfg5's grad_filter: 3.54 MB
+    big[rank::7] += 0.5
+    distributed.allreduce_weight_grads(big)
+    np.save(os.path.join(out_dir, "stack_%d.npy" % rank), st.fused_grad.numpy())
+    np.save(os.path.join(out_dir, "big_%d.npy" % rank), big.numpy())
+    dist.destroy_process_group()
+
+
+def test_stack_fused_buffer_layout_and_cfg5_sized_allreduce(tmp_path):
+    world, B = 2, 5
+    port = _free_port()
+    mp.spawn(_stack_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    from pointwise_amd import stack, synth
+    st = stack.Conv3pStack(3, 13, device="cpu", dtype=torch.float64, seed=9)
+    P = synth.modelnet_like(B, 96, seed=70).astype(np.float64)
+    full = []
+    for li, (ci, co, s) in enumerate(st.layers):
+        X = synth.features(B, 96, ci, 71 + li, dtype=np.float64)
+        dY = synth.upstream_grad(B, 96, co, 81 + li, dtype=np.float64)
+        full.append(oracle.backward(dY, P, X, st.filters[li].numpy(), (s, s, s), 0.1)[1].reshape(-1))
+    full = np.concatenate(full)
+    want_big = np.full(27 * 128 * 256, 3.0, dtype=np.float32)
+    want_big[0::7] += 0.5
+    want_big[1::7] += 0.5
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "stack_%d.npy" % r))
+        assert np.abs(got - full).max() <= 1e-12 * max(1.0, np.abs(full).max())
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "big_%d.npy" % r)), want_big)
+
+
 @pytest.mark.parametrize("B", [6, 5])
 def test_sharded_weight_grads_allreduce_to_full_batch(tmp_path, B):
     world = 2
