@@ -322,6 +322,25 @@ int conv3p_augment_f32(const float *points_in, const double *cos_sin, const doub
 int conv3p_sort_xyz_order_f32(const float *data, int B, int N, int row_floats, int32_t *order, void *stream);
 int conv3p_gather_rows(const void *src, const int32_t *order, int B, int N, int row_bytes, void *dst, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The dense head of the classification model (/root/reference/pointcnn2_acsd.py:69-75:
+ * view (B, N*36) -> fully_connected 512, selu -> dropout_selu -> fully_connected num_class, selu).
+ * tf.contrib.layers.fully_connected is y = activation(x . W + b) with W of shape (K, N).
+ *
+ * conv3p_fc_forward_f32   y (M, N) = act(x (M, K) . W (K, N) + b (N));  act: 0 = identity, 1 = SELU; b may be NULL.
+ * conv3p_fc_backward_f32  given y (the forward OUTPUT) and dy = dL/dy:  dW (K, N) = x^T . dz,  db (N) = sum_m dz,
+ *                         dx (M, K) = dz . W^T  with dz = dy * act'(y);  dx and db may be NULL.
+ * W is streamed exactly once per pass (it is the 151 MB object of the model); products are exact fp32 on the
+ * matrix cores; results are bitwise reproducible.  Constraints: N % 8 == 0, N <= 1024, M <= 128
+ * (CONV3P_ERR_UNSUPPORTED otherwise).  Scratch from conv3p_fc_workspace_bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t conv3p_fc_workspace_bytes(int M, int K, int N);
+int conv3p_fc_forward_f32(const float *x, const float *W, const float *b, int M, int K, int N, int act, float *y,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int conv3p_fc_backward_f32(const float *x, const float *W, const float *y, const float *dy, int M, int K, int N,
+                           int act, float *dx, float *dW, float *db, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* Kernel-level timing with HIP events recorded on the caller's stream (bench.py uses it
  * to derive the roofline of the dominant kernel).  Off by default; when enabled every
  * kernel launch of this library is bracketed by an event pair.  read() synchronises the

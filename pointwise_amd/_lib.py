@@ -63,6 +63,9 @@ class StackDesc(ctypes.Structure):
 
 
 SYMBOLS = {
+    "conv3p_fc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "conv3p_fc_forward_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "conv3p_fc_backward_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "conv3p_augment_f32": (_i, [_vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _i, _i, _vp, _vp]),
     "conv3p_sort_xyz_order_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "conv3p_gather_rows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -16,6 +16,7 @@
 #include "../../include/conv3p.h"
 #include "conv3p_kernels.hpp"
 #include "conv3p_prestep.hpp"
+#include "conv3p_head.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -34,11 +35,12 @@ inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
 // ----------------------------------------------------------------------------- profiling
 enum Kind { K_PREP = 0, K_SEARCH, K_FORWARD, K_BACKWARD, K_REDUCE, K_SELU, K_SELU_GRAD, K_MEMSET,
-            K_DEEP_GEMM, K_DEEP_DW, K_TRANSPOSE, K_DEEP_ORDER, K_NKINDS };
+            K_DEEP_GEMM, K_DEEP_DW, K_TRANSPOSE, K_DEEP_ORDER, K_FC_FWD, K_FC_DX, K_FC_DW, K_NKINDS };
 const char *const kKindName[K_NKINDS] = {"prep_kernel", "search_kernel", "forward_kernel",
                                          "backward_kernel", "reduce_partials_kernel", "selu_kernel",
                                          "selu_grad_kernel", "memset", "deep_gemm_kernel", "deep_dw_kernel",
-                                         "transpose_filter_kernel", "deep_order_kernel"};
+                                         "transpose_filter_kernel", "deep_order_kernel", "fc_forward_kernel",
+                                         "fc_dx_kernel", "fc_dw_kernel"};
 struct Prof {
     std::mutex mu;
     bool on = false;
@@ -1491,6 +1493,97 @@ int conv3p_gather_rows(const void *src, const int32_t *order, int B, int N, int 
     const unsigned grid = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const char *>(src), order, N, row_bytes, static_cast<char *>(dst), rows);
+    return hip_ok();
+}
+
+namespace {
+struct FcPlan { int kc, chunks, mblocks, nblocks; size_t part_bytes, dz_bytes; };
+bool fc_plan(int M, int K, int N, FcPlan &p)
+{
+    if (M < 1 || K < 1 || N < 1 || (N % 8) != 0 || N > 1024 || M > 128) return false;
+    int kc = (K + 255) / 256;                     // ~256 workgroups along K ...
+    kc = (kc + 1) & ~1;
+    if (kc < 32) kc = 32;
+    if (kc > 480) kc = 480;                       // ... with the x chunk [32][kc + 1] within 64 KiB of LDS
+    p.kc = kc;
+    p.chunks = (K + kc - 1) / kc;
+    p.mblocks = (M + 31) / 32;
+    p.nblocks = (N + kFcCols - 1) / kFcCols;
+    p.part_bytes = up((size_t)p.chunks * p.mblocks * 32 * N * 4);
+    p.dz_bytes = up((size_t)M * N * 4);
+    return true;
+}
+}  // namespace
+
+size_t conv3p_fc_workspace_bytes(int M, int K, int N)
+{
+    FcPlan p;
+    if (!fc_plan(M, K, N, p)) return 0;
+    return p.part_bytes > p.dz_bytes ? p.part_bytes : p.dz_bytes;
+}
+
+int conv3p_fc_forward_f32(const float *x, const float *W, const float *b, int M, int K, int N, int act, float *y,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (M < 0 || K < 0 || N < 0 || (act != 0 && act != 1)) return CONV3P_ERR_INVALID_ARGUMENT;
+    if ((size_t)M * N == 0) return CONV3P_OK;
+    if (!x || !W || !y || K == 0) return CONV3P_ERR_INVALID_ARGUMENT;
+    FcPlan p;
+    if (!fc_plan(M, K, N, p)) return CONV3P_ERR_UNSUPPORTED;
+    TRY(buf_check(workspace, workspace_bytes, p.part_bytes));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *part = static_cast<float *>(workspace);
+    {
+        Scope sc(K_FC_FWD, s);
+        const int psteps = ((p.kc + 1) / 2 + kFcDepth - 1) / kFcDepth * kFcDepth;
+        const size_t lds = (size_t)32 * (2 * psteps + 1) * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fc_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(fc_forward_kernel, dim3((unsigned)p.chunks, (unsigned)p.mblocks, (unsigned)p.nblocks), dim3(256), lds, s,
+                           x, W, M, K, N, p.kc, part);
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(fc_finish_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, s, part, b, M, N, p.chunks,
+                           p.mblocks, act, y);
+    }
+    return hip_ok();
+}
+
+int conv3p_fc_backward_f32(const float *x, const float *W, const float *y, const float *dy, int M, int K, int N,
+                           int act, float *dx, float *dW, float *db, void *workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    if (M < 0 || K < 0 || N < 0 || (act != 0 && act != 1)) return CONV3P_ERR_INVALID_ARGUMENT;
+    if ((size_t)K * N == 0) return CONV3P_OK;
+    if (M == 0) return zero_async(dW, (size_t)K * N * 4, static_cast<hipStream_t>(stream));
+    if (!x || !W || !dy || !dW || (act && !y)) return CONV3P_ERR_INVALID_ARGUMENT;
+    FcPlan p;
+    if (!fc_plan(M, K, N, p)) return CONV3P_ERR_UNSUPPORTED;
+    TRY(buf_check(workspace, workspace_bytes, p.dz_bytes));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *dz = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(fc_dz_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, y, dy, M, N, act, dz, db);
+    TRY(hip_ok());
+    {
+        Scope sc(K_FC_DW, s);
+        auto launch = [&](auto kern, int steps) {
+            const size_t lds = (size_t)2 * steps * (N + 1) * 4;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((K + 127) / 128)), dim3(256), lds, s, x, dz, M, K, N, dW);
+        };
+        if (M <= 32) launch(fc_dw_kernel<16>, 16);
+        else if (M <= 64) launch(fc_dw_kernel<32>, 32);
+        else {
+            if ((size_t)128 * (N + 1) * 4 > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
+            launch(fc_dw_kernel<64>, 64);
+        }
+    }
+    TRY(hip_ok());
+    if (dx != nullptr) {
+        Scope sc(K_FC_DX, s);
+        const int psteps = (N / 8 + 15) / 16 * 16;
+        const size_t lds = (size_t)32 * (8 * psteps + 4) * 4 + (size_t)4 * 32 * 33 * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fc_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(fc_dx_kernel, dim3((unsigned)((K + 127) / 128), (unsigned)p.mblocks), dim3(256), lds, s, dz, W, M, K, N, dx);
+    }
     return hip_ok();
 }
 
