@@ -101,6 +101,42 @@ def test_stack_fused_buffer_layout_and_cfg5_sized_allreduce(tmp_path):
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "big_%d.npy" % r)), want_big)
 
 
+def _shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from pointwise_amd import distributed
+    distributed.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(11)
+    W = torch.randn(1001, 8, generator=g, dtype=torch.float64)          # numel not divisible by the world size
+    grads = [torch.randn(1001, 8, generator=g, dtype=torch.float64) for _ in range(world)]
+    lo, hi = distributed.shard_range(W.numel(), world, rank)
+    mom = torch.zeros(hi - lo, dtype=torch.float64)
+    for _ in range(2):                                                   # two steps: the momentum state carries over
+        distributed.sharded_momentum_step(W, grads[rank].clone(), mom, lr=0.1, momentum=0.9)
+    np.save(os.path.join(out_dir, "w_%d.npy" % rank), W.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_momentum_step_equals_all_reduce_training(tmp_path, world):
+    """Reduce-scatter + sharded momentum update + all-gather of a large parameter reproduces the plain
+    all-reduce + full update on every rank (the head's fc1 path in data-parallel training)."""
+    port = _free_port()
+    mp.spawn(_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(11)
+    W = torch.randn(1001, 8, generator=g, dtype=torch.float64)
+    grads = [torch.randn(1001, 8, generator=g, dtype=torch.float64) for _ in range(world)]
+    total = sum(grads)
+    acc = torch.zeros_like(W)
+    for _ in range(2):
+        acc = 0.9 * acc + total
+        W = W - 0.1 * acc
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "w_%d.npy" % r))
+        assert np.abs(got - W.numpy()).max() <= 1e-12
+
+
 @pytest.mark.parametrize("B", [6, 5])
 def test_sharded_weight_grads_allreduce_to_full_batch(tmp_path, B):
     world = 2
