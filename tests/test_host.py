@@ -151,3 +151,13 @@ def test_shard_bounds():
     assert distributed.shard_bounds(2, 4, 3) == (2, 2)
     with pytest.raises(ValueError):
         distributed.shard_bounds(8, 2, 2)
+
+
+def test_tf_shim_is_well_formed_against_the_declared_api():
+    """integration/tf_conv3p_shim.cc type-checks (-fsyntax-only) against include/conv3p.h and the declared subset of
+    the TensorFlow op API (integration/tf_decl).  Not a TensorFlow build -- there is none in this image -- but it
+    keeps the shim's C-ABI calls in step with the header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(["make", "-C", os.path.join(root, "integration"), "check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
