@@ -503,6 +503,7 @@ struct DeepScratch {   // carved from the per-call scratch region
     uint2 *tap_rng;        // [64] partial slots of each tap
     uint4 *items;          // [kDwItems + 64] deep_dw_kernel work items
     float *partials;       // [kDwItems + 64][Cin*Cout] item partials, then [F*Cin*Cout] the generic kernel's share
+    float *gbuf;           // [tiles][F][64][Coutpad]: G_f' of every (tile, backward tap), grad_input -> grad_filter pass
     size_t bytes;
 };
 
@@ -524,6 +525,7 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     s.tap_rng = reinterpret_cast<uint2 *>(take(64 * 8));
     s.items = reinterpret_cast<uint4 *>(take((size_t)(kDwItems + 64) * 16));
     s.partials = reinterpret_cast<float *>(take((size_t)(kDwItems + 64) * cip * cop * 4 + nw * 4));
+    s.gbuf = reinterpret_cast<float *>(take((size_t)d.B * d.ntiles * d.ntap * 64 * cop * 4));
     s.bytes = off;
     return s;
 }
@@ -550,12 +552,11 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
 
 template <int KD, int ND, bool BWD>
 int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, float *out, const DeepScratch &ds,
-                     int kreal, int nreal)
+                     int kreal, int nreal, float *gbuf = nullptr, const float *xin = nullptr)
 {
     const Dims &d = c.d;
     const auto &S = c.L.slot[c.slot];
-    const size_t a = (size_t)64 * (KD + 1) * 4, r = (size_t)kDeepBlk * (KD + 32) * 4;
-    const size_t lds = a16(a > r ? a : r) + 3 * (size_t)kDeepBatch * 4 + 256;
+    const size_t lds = a16((size_t)(KD < 256 ? 256 / KD : 1) * 64 * (KD + 1) * 4) + 3 * (size_t)kDeepBatch * 4 + 256 + 1024;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_DEEP_GEMM, c.s);
@@ -563,7 +564,7 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((deep_gemm_kernel<KD, ND, BWD>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs,
                        S.segs, src, Bm, d.N, d.ntiles, d.ntap, ds.sched, ds.sched_cap, out, ds.tap_meta, ds.tap_off,
-                       ds.tile_flag, kreal, nreal);
+                       ds.tile_flag, kreal, nreal, gbuf, xin);
     return hip_ok();
 }
 
@@ -604,17 +605,17 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
     TRY(launch_deep_order<true>(c, ds));
     TRY(launch_pad_filter(c, filter, CO, CI, 1, ds.wt));
     // dX = sum_f' G_f' . W[f']^T  (K = Cout, N = Cin)
-    TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds, d.Cout, d.Cin)));
+    TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds, d.Cout, d.Cin, ds.gbuf, input)));
     {
-        const size_t lds = a16((size_t)65 * (CI + 1) * 4) + a16((size_t)kDeepBlk * (CO + 32) * 4) +
-                           3 * (size_t)kDeepBatch * 4 + 256 + ((CONV3P_ABLATE & 8388608) ? 20000 : 0);
+        constexpr int NH = CO >= 64 ? 2 : 1;
+        const size_t lds = (size_t)64 * (CI + 1) * 4 + (size_t)64 * (CO / NH + 1) * 4 + 256;
         if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
         Scope sc(K_DEEP_DW, c.s);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_dw_kernel<CI, CO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(kDwItems + 64), dim3(256), lds, c.s, c.L.pts, S.pairs, S.segs,
-                           ds.tap_meta, ds.tap_off, grad_out, input, d.B, d.N, d.ntiles, d.ntap, ds.tile_flag, ds.items,
-                           ds.tap_total + 64, ds.partials, d.Cin, d.Cout);
+        hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(kDwItems + 64, NH), dim3(256), lds, c.s, c.L.pts, ds.tap_off,
+                           ds.gbuf, input, d.N, d.ntiles, d.ntap, ds.tile_flag, ds.items, ds.tap_total + 64, ds.partials,
+                           d.Cin);
     }
     TRY(hip_ok());
     // flagged tiles: generic kernel adds into the zeroed rows / into its own grad_filter-shaped buffer

@@ -13,8 +13,10 @@
 //   * M_f = S_f . rows, where S_f[centre][record] = 1/count if the record belongs to the centre, else 0, is built
 //     in the A-operand registers on the fly (one compare + select per MFMA step);
 //   * M_f . W[f] follows from LDS, the W[f] operand streamed from L2 sixteen k-rows ahead;
-//   * dW[f'] = X_tile^T . (dY rows / count) needs no per-centre reduction at all: the pair index is the GEMM's
-//     k dimension.
+//   * dW[f'] = sum over tiles of X_tile^T . G_f'[tile]: the grad_input kernel leaves every G_f' tile ([64][Cout], the
+//     per-centre reduction it computes anyway) in a scratch buffer, and the grad_filter kernel is a plain
+//     [Cin x 64] . [64 x Cout] product per (tile, tap) -- 2*27*Cin*Cout flops per point, the dense-equivalent count
+//     (the earlier pair-indexed form issued 3.6x that).
 // Taps with no neighbour in the tile are skipped.
 // Channel counts: the kernels are instantiated for KDIM, NDIM in {32, 64, 128} (+ the 128 -> 256 layer) and take the
 // REAL row lengths at run time: rows are read / written with their real length and stride, columns past the real
@@ -226,6 +228,11 @@ __global__ __launch_bounds__(1024) void deep_sched_kernel(const uint2 *__restric
     for (int i = threadIdx.x; i < cap; i += blockDim.x) out[i] = i < n ? (uint32_t)keys[i] : 0xFFFFFFFFu;
 }
 
+__device__ __forceinline__ int qorig_early(const PointRec<float> *__restrict__ pts, size_t tile_id, int q)
+{
+    return pts[tile_id * kTile + q].idx;
+}
+
 // metadata of up to kDeepBatch records of one (tile, tap) run -> LDS (thread = record: one coalesced load).
 // mqr[t] = {centre lane, bits of 1/count}; entries past the run: row 0 (never loaded), centre 64 (matches no
 // lane; row 64 of deep_dw_kernel's X tile is all zero), weight 0.
@@ -269,10 +276,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                                                         const uint2 *__restrict__ tap_meta,
                                                         const uint32_t *__restrict__ tap_off,
                                                         uint8_t *__restrict__ tile_flag,
-                                                        int kreal, int nreal)   // real row lengths of src / out
+                                                        int kreal, int nreal,   // real row lengths of src / out
+                                                        float *__restrict__ gbuf,   // BWD: [tile][tap][64][KDIM] <- M_f
+                                                        const float *__restrict__ xin)   // BWD: the layer's input
 {
     constexpr int LDA = KDIM + 1;
-    constexpr int LDR = KDIM + 32;                        // half-waves read different rows: 32 banks apart
+    constexpr int kGroups = KDIM < 256 ? 256 / KDIM : 1;   // copies of M_f (stage 1's thread groups, one per 256 / KDIM)
     // 32x32 blocks of M_f (2 x KDIM/32) and of the output (2 x NDIM/32) are dealt to the 4 waves so that every
     // index below is a compile-time constant (accumulators stay in AGPRs, no predicated MFMAs): wave w owns the
     // row block w & 1 and the column blocks (w >> 1) + 2j.  With a single column block (32 channels) only
@@ -281,19 +290,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     constexpr int SPW = CBK >= 2 ? CBK / 2 : 1;           // ... per wave
     constexpr int CBN = NDIM / 32;                        // column blocks of the output
     constexpr int OPW = CBN >= 2 ? CBN / 2 : 1;
-    constexpr int F4 = KDIM / 4;                          // float4 per row
-    constexpr int RPT = (kDeepBlk * F4) / 256;            // float4 per thread and block (KDIM >= 32)
     constexpr int KG = 8;                                 // MFMA k-steps per B-operand prefetch group
-    static_assert(KDIM % 32 == 0 && NDIM % 32 == 0 && RPT >= 1 && (CBK == 1 || CBK % 2 == 0) && (CBN == 1 || CBN % 2 == 0),
+    static_assert(KDIM % 32 == 0 && NDIM % 32 == 0 && KDIM <= 256 && (CBK == 1 || CBK % 2 == 0) && (CBN == 1 || CBN % 2 == 0),
                   "deep path: channel counts are 32 or multiples of 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *A = reinterpret_cast<float *>(smem);           // stage 2
-    float *R = reinterpret_cast<float *>(smem);           // stage 1 (same bytes)
-    constexpr size_t kUnion = (size_t)64 * LDA * 4 > (size_t)kDeepBlk * LDR * 4 ? (size_t)64 * LDA * 4 : (size_t)kDeepBlk * LDR * 4;
-    size_t off = align16(kUnion);
+    float *A = reinterpret_cast<float *>(smem);           // M_f [kGroups][64][LDA] (partial sums, added on read)
+    size_t off = align16((size_t)kGroups * 64 * LDA * 4);
     uint2 *mqr = reinterpret_cast<uint2 *>(smem + off);
     uint32_t *mcand = reinterpret_cast<uint32_t *>(mqr + kDeepBatch);
     int32_t *qorig = reinterpret_cast<int32_t *>(mcand + kDeepBatch);
+    float *scrap = reinterpret_cast<float *>(qorig + 64);   // [256] write-only (stage 1's predicated-off stores)
 
     // workgroup -> tile: XCD (blockIdx.x & 7, as in BlockMap) and position in that XCD's longest-first order
     const uint32_t tile_sched = sched[(size_t)(blockIdx.x & 7) * sched_cap + (blockIdx.x >> 3)];
@@ -327,31 +333,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    // rows of one block -> registers (float4 per thread: row = e / F4, column = 4 * (e % F4)); rows past the
-    // batch's last record are zero.  S_f multiplies every staged row by 0 for the centres it does not belong to,
-    // which is only harmless for finite values: a non-finite row sends the whole tile to the exact generic
-    // kernel instead (tile_flag), so that NaN / Inf reach exactly the outputs they reach in the reference.
+    // Tiles that meet a non-finite value are handed to the exact generic kernel (tile_flag), so that NaN / Inf
+    // reach exactly the outputs they reach in the reference whatever the association of the sums.
     float badsum = 0.0f;
-    auto load_rows = [&](uint32_t p0, uint32_t nrec, float4 (&rv)[RPT]) {
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int e = (int)threadIdx.x + 256 * u;
-            const uint32_t p = p0 + (uint32_t)(e / F4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < nrec) v = load_row4(src_cloud + (size_t)mcand[p] * kreal, 4 * (e % F4), kreal);
-            rv[u] = v;                                   // nothing here may consume v: the loads stay in flight
+    // grad_input pass: the grad_filter kernel will multiply ALL 64 input rows of this tile with G_f' (zero rows for
+    // centres without that tap), which is exact only for finite inputs -- a non-finite input row sends the tile to
+    // the generic kernel as well
+    if (BWD && xin != nullptr) {
+        const float *xc = xin + (size_t)b * N * nreal;
+        for (int e = threadIdx.x; e < 64 * nreal; e += 256) {
+            const int orig = qorig_early(pts, tile_id, e / nreal);
+            if (orig >= 0) {
+                const float v = xc[(size_t)orig * nreal + (e % nreal)];
+                badsum += v - v;
+            }
         }
-    };
-    auto store_rows = [&](const float4 (&rv)[RPT]) {
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int e = (int)threadIdx.x + 256 * u;
-            const float4 v = rv[u];
-            badsum += ((v.x - v.x) + (v.y - v.y)) + ((v.z - v.z) + (v.w - v.w));   // 0 for finite values, NaN otherwise
-            *reinterpret_cast<float4 *>(R + (e / F4) * LDR + 4 * (e % F4)) = v;
-        }
-    };
-
+    }
 #if CONV3P_ABLATE & 16777216
     long long gk[6] = {0, 0, 0, 0, 0, 0};
     long long gblk = 0, gtap = 0;
@@ -363,70 +360,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     for (int f = 0; f < ntap; ++f) {
         const uint32_t e0 = toff[f], e1 = toff[f + 1];
         if (e0 == e1) continue;                              // block-uniform
-        // ---- stage 1: M_f = S_f . rows
-        f32x16 am[SPW];
+        // ---- stage 1: M_f[centre] = sum over the centre's records of this tap of row[neighbour] / count.
+        // A tap's records are centre-major (the search's order, kept by the stable sort of deep_order_kernel), so
+        // this is a segmented sum.  Thread = one column (with KDIM < 256 the 256 / KDIM thread groups take one
+        // slice of the centres each); it walks the run, adds the neighbour's value (straight from global memory: a
+        // row is one coalesced read of the group) to a running sum that restarts at every change of centre, and
+        // stores the running sum to M_f[centre] after EVERY record -- the last store of a centre is its total.  No
+        // branch in the loop: selects, one fma, one 4-byte LDS store per record and thread, where the selection
+        // product S_f . rows spent 64 x KDIM x 2 matrix-core flops per record.  Exact for any values.
+        __syncthreads();                                     // previous tap's stage 2 has read A; meta free
+        for (int e = threadIdx.x; e < kGroups * 64 * LDA; e += 256) A[e] = 0.0f;
+        {
+            // With KDIM < 256 the kGroups = 256 / KDIM threads of a column take every kGroups-th record of the run
+            // (each one's subsequence is still centre-major) and keep their partial sums in separate copies of M_f,
+            // added when stage 2 reads them: every thread has a load to issue at every step.
+            const int col = (int)threadIdx.x % KDIM, grp = (int)threadIdx.x / KDIM;
+            const bool col_ok = col < kreal;
+            float *Ag = A + grp * 64 * LDA + col;
+            float *dummy = scrap + threadIdx.x;              // where the stores of steps past the run's end go
+            float sum = 0.0f;
+            uint32_t prev = 64;                              // centre of the running sum (64 = none)
+            for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
+                if (eb != e0) __syncthreads();               // previous batch's metadata consumed
+                deep_fetch_meta(meta, eb, e1, mcand, mqr);
+                __syncthreads();                             // (first batch: also orders the zeroing of A)
+                GDBG(0)
+                const uint32_t nrec = (CONV3P_ABLATE & 32768) ? 0u : min((uint32_t)kDeepBatch, e1 - eb);
+                constexpr int kU = 16;                       // records per thread and step; two steps in flight
+                auto fetch = [&](uint32_t p0, float (&v)[kU], float (&w)[kU], uint32_t (&q)[kU]) {
 #pragma unroll
-        for (int j = 0; j < SPW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) am[j][r] = 0.0f;
-        for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
-            __syncthreads();                                 // meta / LDS union free
-            deep_fetch_meta(meta, eb, e1, mcand, mqr);
-            __syncthreads();
-            GDBG(0)
-            const uint32_t nrec = min((uint32_t)kDeepBatch, e1 - eb);
-            float4 rv[RPT];
-            load_rows(0, nrec, rv);
-            for (uint32_t p0 = 0; p0 < nrec; p0 += kDeepBlk) {
-                store_rows(rv);
-                __syncthreads();
-                GDBG(1)
-                if (p0 + kDeepBlk < nrec) load_rows(p0 + kDeepBlk, nrec, rv);   // in flight under the MFMAs below
-                if (s_on && !(CONV3P_ABLATE & 32768)) {
-                    // always the block's 16 k-steps (rows past the last record are zero, their weight is 0):
-                    // straight-line code, every LDS operand of a group of 4 steps in flight before its MFMAs
-                    const float *rrow = R + (lane >> 5) * LDR + cb0 * 32 + (lane & 31);
-                    const uint2 *mrow = mqr + p0 + (uint32_t)(lane >> 5);
-#pragma unroll
-                    for (int s4 = 0; s4 < kDeepBlk / 2; s4 += 4) {
-                        uint2 m[4];
-                        float bv[4][SPW];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            m[t] = mrow[2 * (s4 + t)];
-#pragma unroll
-                            for (int j = 0; j < SPW; ++j) bv[t][j] = rrow[2 * (s4 + t) * LDR + j * 64];
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            // S_f operand: 1/count where the record belongs to this lane's centre, else 0
-                            const float sv = m[t].x == myrow ? __builtin_bit_cast(float, m[t].y) : 0.0f;
-#pragma unroll
-                            for (int j = 0; j < SPW; ++j)
-                                am[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, bv[t][j], am[j], 0, 0, 0);
-                        }
+                    for (int u = 0; u < kU; ++u) {
+                        const uint32_t p = p0 + (uint32_t)(u * kGroups + grp);
+                        const bool in = p < nrec;
+                        const uint2 m = mqr[in ? p : 0];
+                        q[u] = in ? m.x : 64u;
+                        w[u] = __builtin_bit_cast(float, m.y);
+                        v[u] = 0.0f;
+                        if (in && col_ok) v[u] = src_cloud[(size_t)mcand[in ? p : 0] * kreal + col];
                     }
+                };
+                auto consume = [&](const float (&v)[kU], const float (&w)[kU], const uint32_t (&q)[kU]) {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const bool in = q[u] != 64u;
+                        badsum += v[u] - v[u];               // 0 for finite values, NaN otherwise (see the epilogue)
+                        const float t = q[u] == prev ? __builtin_fmaf(v[u], w[u], sum) : v[u] * w[u];
+                        sum = in ? t : sum;
+                        prev = in ? q[u] : prev;
+                        float *dst = in ? Ag + q[u] * LDA : dummy;
+                        *dst = sum;
+                    }
+                };
+                float va[kU], wa[kU], vb[kU], wb[kU];
+                uint32_t qa[kU], qb[kU];
+                constexpr uint32_t kStep = (uint32_t)(kU * kGroups);
+                fetch(0, va, wa, qa);
+                for (uint32_t p0 = 0; p0 < nrec; p0 += 2 * kStep) {
+                    fetch(p0 + kStep, vb, wb, qb);
+                    consume(va, wa, qa);
+                    fetch(p0 + 2 * kStep, va, wa, qa);
+                    consume(vb, wb, qb);
                 }
-                GDBG(2)
-                __syncthreads();                             // rows consumed
-                GDBG(3)
-#if CONV3P_ABLATE & 16777216
-                gblk++;
-#endif
             }
         }
 #if CONV3P_ABLATE & 16777216
         gtap++;
 #endif
-        // M_f fragments -> LDS [64][LDA]
-        if (s_on) {
+        __syncthreads();                                     // M_f complete in LDS [64][LDA]
+        // grad_input pass: M_f (= G_f' of this tile) also goes to gbuf, the grad_filter kernel's B operand
+        if (BWD && gbuf != nullptr) {
+            float *gt = gbuf + (tile_id * (size_t)ntap + f) * 64 * KDIM;
+            for (int e = threadIdx.x; e < 64 * KDIM; e += 256) {
+                float g = A[(e / KDIM) * LDA + (e % KDIM)];
 #pragma unroll
-            for (int j = 0; j < SPW; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    A[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDA + (cb0 + 2 * j) * 32 + (lane & 31)] = am[j][r];
+                for (int gi = 1; gi < kGroups; ++gi) g += A[gi * 64 * LDA + (e / KDIM) * LDA + (e % KDIM)];
+                gt[e] = g;
+            }
         }
-        __syncthreads();
         GDBG(4)
         // ---- stage 2: out += M_f . Bm[f]   (B operand from L2, one group of KG k-steps ahead)
         if (o_on) {
@@ -444,7 +454,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                 if (k0 + 2 * KG < KDIM) load_b(k0 + 2 * KG, bn);
 #pragma unroll
                 for (int s = 0; s < KG; ++s) {
-                    const float a = arow[k0 + 2 * s];
+                    float a = arow[k0 + 2 * s];
+#pragma unroll
+                    for (int gi = 1; gi < kGroups; ++gi) a += arow[gi * 64 * LDA + k0 + 2 * s];
 #pragma unroll
                     for (int j = 0; j < OPW; ++j)
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[s][j], acc[j], 0, 0, 0);
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restr
             w[u] = 0;
             if (u < per && t < T) {
                 const uint32_t c = tap_off[(size_t)t * (ntap + 1) + f + 1] - tap_off[(size_t)t * (ntap + 1) + f];
-                w[u] = c ? (c + 31u) / 32u + 2u : 0u;         // blocks of 32 records + the tile's fixed cost
+                w[u] = c ? 1u : 0u;                           // one [Cin x 64].[64 x Cout] product per populated tile
             }
             mine += w[u];
         }
@@ -648,48 +660,39 @@ __global__ __launch_bounds__(256) void deep_reduce_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// deep_dw_kernel: grad_filter partials.  Workgroup = (backward tap f, chunk of query tiles):
-//   dW[f][0..CIN)[0..COUT) = sum over the chunk's records of tap f:  x[centre]^T (CIN x 1) . dY[neighbour] / count
-// i.e. a [CIN x P].[P x COUT] GEMM whose k dimension is the record index: per tile the X tile is in LDS (the A
-// operand of record p is row `centre(p)` of it), the dY rows of 32 records at a time are copied into LDS already
-// multiplied by 1/count (the next block's loads in flight under the MFMAs).  The waves form a WM x WN grid over
-// the CIN/32 x COUT/32 output blocks; accumulators stay in registers over the whole chunk; one partial per
-// chunk, summed by reduce_partials_kernel in fixed order.
-// LDS: X tile [64][CIN+1] | rows [32][COUT+32] | meta [256] x 3 | qorig [64]
+// deep_dw_kernel: grad_filter partials.  Workgroup = (work item = backward tap f and a range of query tiles,
+// half of the output columns):
+//   dW[f][0..CIN)[cols] = sum over the item's tiles of  X_tile^T [CIN x 64] . G_f[tile] [64 x cols]
+// G_f[tile] (row j = sum over the pairs of centre j with backward tap f of dY[neighbour] / count) was stored by the
+// grad_input pass of deep_gemm_kernel; rows of X by the centres' original indices.  32 MFMA k-steps per tile, the
+// waves form a WM x WN grid over the CIN/32 x cols/32 output blocks, accumulators stay in registers over the whole
+// item; one partial per item ([CIN][COUT], each half writes its columns), summed by deep_reduce_kernel in fixed order.
+// LDS: X tile [64][CIN+1] | G tile [64][cols+1] | qorig [64]   (<= 66 KB: two workgroups per CU)
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void deep_dw_kernel(
-    const PointRec<float> *__restrict__ pts, const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs,
-    const uint2 *__restrict__ tap_meta, const uint32_t *__restrict__ tap_off, const float *__restrict__ grad_out,
-    const float *__restrict__ input, int B, int N, int ntiles, int ntap, const uint8_t *__restrict__ tile_flag,
+    const PointRec<float> *__restrict__ pts, const uint32_t *__restrict__ tap_off, const float *__restrict__ gbuf,
+    const float *__restrict__ input, int N, int ntiles, int ntap, const uint8_t *__restrict__ tile_flag,
     const uint4 *__restrict__ items, const uint32_t *__restrict__ nitems, float *__restrict__ partials,
-    int cin, int cout)   // real channel counts (<= CIN, COUT); the partial slots are [CIN][COUT]
+    int cin)   // real input channels (<= CIN); the partial slots are [CIN][COUT]
 {
-    constexpr int LDX = CIN + 1;
-    constexpr int LDR = COUT + 32;
-    constexpr int MB = CIN / 32, NB = COUT / 32;
+    constexpr int NH = COUT >= 64 ? 2 : 1;                 // column halves (blockIdx.y)
+    constexpr int CH = COUT / NH;
+    constexpr int LDX = CIN + 1, LDG = CH + 1;
+    constexpr int MB = CIN / 32, NB = CH / 32;
     constexpr int WN = NB >= 4 ? 4 : NB, WM = 4 / WN;      // wave grid
     constexpr int PM = (MB + WM - 1) / WM, PN = NB / WN;   // blocks per wave along each axis
-    static_assert(NB % WN == 0 && (MB % WM == 0 || MB < WM), "deep path: channel counts are 32 or multiples of 64");
-    constexpr int F4 = COUT / 4;
-    constexpr int RPT = (kDeepBlk * F4) / 256;
-    static_assert(CIN % 32 == 0 && COUT % 32 == 0 && RPT >= 1, "deep path: channel counts are multiples of 32");
+    static_assert(CIN % 32 == 0 && CH % 32 == 0 && NB % WN == 0, "deep path: channel counts are 32 or multiples of 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *X = reinterpret_cast<float *>(smem);          // [65][LDX]: row 64 stays zero (padding records)
-    size_t off = align16((size_t)65 * LDX * 4);
-    float *R = reinterpret_cast<float *>(smem + off);
-    off += align16((size_t)kDeepBlk * LDR * 4);
-    uint2 *mqr = reinterpret_cast<uint2 *>(smem + off);
-    uint32_t *mcand = reinterpret_cast<uint32_t *>(mqr + kDeepBatch);
-    int32_t *qorig = reinterpret_cast<int32_t *>(mcand + kDeepBatch);
-    for (int e = threadIdx.x; e < LDX; e += 256) X[64 * LDX + e] = 0.0f;
-
+    float *X = reinterpret_cast<float *>(smem);            // [64][LDX]
+    float *G = X + 64 * LDX;                               // [64][LDG]
+    int32_t *qorig = reinterpret_cast<int32_t *>(G + 64 * LDG);
     if (blockIdx.x >= *nitems) return;
     const uint4 item = items[blockIdx.x];                  // {tap, first tile, end tile, partial slot}
-    const int f = (int)item.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = (int)item.x, c0 = (int)blockIdx.y * CH;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const bool w_on = MB % WM == 0 || wm < MB;             // (32-channel inputs: only the first row of waves)
+    const bool w_on = wm * PM < MB;
     f32x16 acc[PM][PN];
 #pragma unroll
     for (int i = 0; i < PM; ++i)
@@ -698,30 +701,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const size_t t0 = item.y, t1 = item.z;
-#if CONV3P_ABLATE & 16777216
-    long long tk[6] = {0, 0, 0, 0, 0, 0};
-    long long nblk_dbg = 0, ntile_dbg = 0;
-#define DBG_T(i) { const long long t_ = wall_clock64(); tk[i] += t_ - tlast; tlast = t_; }
-    long long tlast = wall_clock64();
-#else
-#define DBG_T(i)
-#endif
-    for (size_t tile = t0; tile < t1; ++tile) {
+    for (size_t tile = item.y; tile < item.z; ++tile) {
         const uint32_t *toff = tap_off + tile * (size_t)(ntap + 1);
-        const uint32_t e0 = toff[f], e1 = toff[f + 1];
-        if (e0 == e1 || tile_flag[tile]) continue;          // uniform: nothing with this tap / generic kernel's tile
+        if (toff[f] == toff[f + 1] || tile_flag[tile]) continue;   // uniform: nothing with this tap / generic kernel's tile
         const int b = (int)(tile / ntiles);
-        const uint2 tseg = segs[tile];
-        const uint2 *meta = tap_meta + tseg.x;
-        const float *dy_cloud = grad_out + (size_t)b * N * cout;
-        DBG_T(0)
-        __syncthreads();                                    // previous tile's X / rows consumed
+        __syncthreads();                                    // previous tile's X / G consumed
         if (wave == 0) qorig[lane] = pts[tile * kTile + lane].idx;
-        deep_fetch_meta(meta, e0, e1, mcand, mqr);
-        __syncthreads();
-        DBG_T(1)
-        // X tile (rows by original index; padding centres -> 0): all of a thread's float4 loads in flight together
+        // G tile half: [64][CH] of the stored [64][COUT] block (16-byte loads, all of a thread's in flight together)
+        {
+            const float *gt = gbuf + (tile * (size_t)ntap + f) * 64 * COUT + c0;
+            constexpr int GPT = (64 * (CH / 4)) / 256;       // float4 per thread
+            float4 gv[GPT];
+#pragma unroll
+            for (int u = 0; u < GPT; ++u) {
+                const int e = (int)threadIdx.x + 256 * u;
+                gv[u] = *reinterpret_cast<const float4 *>(gt + (size_t)(e / (CH / 4)) * COUT + 4 * (e % (CH / 4)));
+            }
+#pragma unroll
+            for (int u = 0; u < GPT; ++u) {
+                const int e = (int)threadIdx.x + 256 * u;
+                float *gr = G + (e / (CH / 4)) * LDG + 4 * (e % (CH / 4));
+                gr[0] = gv[u].x; gr[1] = gv[u].y; gr[2] = gv[u].z; gr[3] = gv[u].w;
+            }
+        }
+        __syncthreads();                                    // qorig visible
         {
             constexpr int XPT = (64 * (CIN / 4)) / 256;      // float4 per thread (CIN >= 32)
             float4 xv[XPT];
@@ -730,8 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
                 const int e = (int)threadIdx.x + 256 * u;
                 const int orig = qorig[e / (CIN / 4)];
                 xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (orig >= 0 && !(CONV3P_ABLATE & 2097152))
-                    xv[u] = load_row4(input + ((size_t)b * N + orig) * cin, 4 * (e % (CIN / 4)), cin);
+                if (orig >= 0) xv[u] = load_row4(input + ((size_t)b * N + orig) * cin, 4 * (e % (CIN / 4)), cin);
             }
 #pragma unroll
             for (int u = 0; u < XPT; ++u) {
@@ -740,84 +742,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
                 xr[0] = xv[u].x; xr[1] = xv[u].y; xr[2] = xv[u].z; xr[3] = xv[u].w;
             }
         }
-        auto load_rows = [&](uint32_t p0, uint32_t nrec, float4 (&rv)[RPT]) {
+        __syncthreads();
+        if (w_on) {
+            // A[i = k][kk = centre] = X[centre][k], B[kk = centre][j = c] = G[centre][c]: 32 k-steps, 4 at a time
+            const float *xa = X + half * LDX + wm * PM * 32 + (lane & 31);
+            const float *gb = G + half * LDG + wn * PN * 32 + (lane & 31);
 #pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                const int e = (int)threadIdx.x + 256 * u;
-                const uint32_t p = p0 + (uint32_t)(e / F4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // rows past the last record contribute nothing
-                if (p < nrec) v = load_row4(dy_cloud + (size_t)mcand[p] * cout, 4 * (e % F4), cout);
-                rv[u] = v;                               // nothing here may consume v: the loads stay in flight
-            }
-        };
-        auto store_rows = [&](uint32_t p0, const float4 (&rv)[RPT]) {
+            for (int s4 = 0; s4 < 32; s4 += 4) {
+                float a[4][PM], bv[4][PN];
 #pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                const int e = (int)threadIdx.x + 256 * u;
-                const float w = __builtin_bit_cast(float, mqr[p0 + (uint32_t)(e / F4)].y);   // dY / count (.cpp:692, :696)
-                float4 v = rv[u];
-                v.x *= w; v.y *= w; v.z *= w; v.w *= w;
-                *reinterpret_cast<float4 *>(R + (e / F4) * LDR + 4 * (e % F4)) = v;
-            }
-        };
-        for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
-            if (eb != e0) {
-                __syncthreads();
-                deep_fetch_meta(meta, eb, e1, mcand, mqr);
-                __syncthreads();
-            }
-            const uint32_t nrec = min((uint32_t)kDeepBatch, e1 - eb);
-            float4 rv[RPT];
-            load_rows(0, nrec, rv);
-            DBG_T(2)
-            for (uint32_t p0 = 0; p0 < nrec; p0 += kDeepBlk) {
-                if (!(CONV3P_ABLATE & 1048576)) store_rows(p0, rv);
-                if (!(CONV3P_ABLATE & 524288)) __syncthreads();                            // rows (and, first time, the X tile) visible
-                DBG_T(3)
-                if (!(CONV3P_ABLATE & 1048576) && p0 + kDeepBlk < nrec) load_rows(p0 + kDeepBlk, nrec, rv);
-                if (w_on && !(CONV3P_ABLATE & 131072)) {
-                    // always the block's 16 k-steps (rows past the last record are zero and pair with the zero
-                    // row 64 of X): straight-line code, a group's LDS operands in flight before its MFMAs
-                    const float *rbase = R + (lane >> 5) * LDR + wn * 32 + (lane & 31);
-                    const uint2 *mrow = mqr + p0 + (uint32_t)(lane >> 5);
+                for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                    for (int s2 = 0; s2 < kDeepBlk / 2; s2 += 2) {
-                        float a[2][PM], bv[2][PN];
+                    for (int i = 0; i < PM; ++i) a[t][i] = xa[2 * (s4 + t) * LDX + i * 32];
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const float *xrow = X + mrow[2 * (s2 + t)].x * LDX + wm * 32 + (lane & 31);
-#pragma unroll
-                            for (int i = 0; i < PM; ++i) a[t][i] = (CONV3P_ABLATE & 262144) ? (float)(i + lane) : xrow[i * WM * 32];
-#pragma unroll
-                            for (int j = 0; j < PN; ++j) bv[t][j] = (CONV3P_ABLATE & 262144) ? (float)(j - lane) : rbase[2 * (s2 + t) * LDR + j * WN * 32];
-                        }
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int i = 0; i < PM; ++i)
-#pragma unroll
-                                for (int j = 0; j < PN; ++j)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][i], bv[t][j], acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < PN; ++j) bv[t][j] = gb[2 * (s4 + t) * LDG + j * 32];
                 }
-                DBG_T(4)
-                if (!(CONV3P_ABLATE & 524288)) __syncthreads();                            // rows consumed
-                DBG_T(5)
-#if CONV3P_ABLATE & 16777216
-                nblk_dbg++;
-#endif
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < PM; ++i)
+#pragma unroll
+                        for (int j = 0; j < PN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][i], bv[t][j], acc[i][j], 0, 0, 0);
             }
         }
-#if CONV3P_ABLATE & 16777216
-        ntile_dbg++;
-#endif
     }
-#if CONV3P_ABLATE & 16777216
-    if (threadIdx.x == 0 && f == 13 && (item.w & 15) == 1)
-        printf("dw dbg (100 MHz ticks): tiles %lld blocks %lld | loop-head %lld  meta %lld  X+rows0 %lld  store+sync %lld  loads+mfma %lld  sync2 %lld\n",
-               ntile_dbg, nblk_dbg, tk[0], tk[1], tk[2], tk[3], tk[4], tk[5]);
-#endif
-
     // partial slot of this item: [k][c]
     float *slot = partials + (size_t)item.w * CIN * COUT;
     if (w_on) {
@@ -827,8 +776,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
             for (int j = 0; j < PN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int k = (wm + WM * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    slot[(size_t)k * COUT + (wn + WN * j) * 32 + (lane & 31)] = acc[i][j][r];
+                    const int k = (wm * PM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (k < CIN) slot[(size_t)k * COUT + c0 + (wn * PN + j) * 32 + (lane & 31)] = acc[i][j][r];
                 }
     }
 }
