@@ -151,6 +151,15 @@ BlockMap make_blockmap(const Dims &d)
     return m;
 }
 inline unsigned grid_of(const BlockMap &m) { return 8u * (unsigned)m.rounds * (unsigned)m.blocks_per_cloud; }
+// register-path backward: kBwdTiles consecutive query tiles per workgroup (one filter staging, one grad_filter
+// partial; for cfg2 the 512 workgroups are exactly what is resident at two per CU)
+constexpr int kBwdTiles = 1;   // measured: 2 tiles per workgroup (half the partials, one resident round) is SLOWER, 0.247 -> 0.306 ms/step -- the kernel is latency-bound per workgroup and wants as many tiles in flight as fit
+BlockMap make_blockmap_bwd(const Dims &d)
+{
+    BlockMap m = make_blockmap(d);
+    m.blocks_per_cloud = (d.ntiles + kBwdTiles - 1) / kBwdTiles;
+    return m;
+}
 
 // ----------------------------------------------------------------------------- buffer layout
 // One layout serves both the per-call workspace (1 slot, rebuilt every call) and the persistent
@@ -442,20 +451,20 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    // reduce buffer [4][CI][64] aliases { Wt | X tile | SoA }
-    size_t tail = (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)64 * CI * sizeof(T)) : 0) + a16((size_t)kWavesPerBlock * 192 * 4);
-    const size_t red = CI > 0 ? a16((size_t)kWavesPerBlock * CI * 64 * sizeof(T)) : 0;
-    if (tail < red) tail = red;
-    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) + a16(256 * sizeof(T)) : 0) + 256 + tail;
+    // LDS: tapmap | max(G [F*CO][65], reduce buffer [4][CI][64]) | qorig | rinv | Wt | X tile | SoA
+    const size_t tail = (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)64 * CI * sizeof(T)) : 0) + a16((size_t)kWavesPerBlock * 192 * 4);
+    const size_t gsz = (size_t)st.ntap * CO * kCntStride, rsz = (size_t)kWavesPerBlock * CI * 64;
+    const size_t lds = lds_common(st) + (CI > 0 ? a16((gsz > rsz ? gsz : rsz) * sizeof(T)) + a16(256 * sizeof(T)) : 0) + 256 + tail;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
-    const BlockMap bm = make_blockmap(d);
+    const int tpw = (CI > 0 && only_flagged == nullptr) ? kBwdTiles : 1;
+    const BlockMap bm = tpw > 1 ? make_blockmap_bwd(d) : make_blockmap(d);
     Scope sc(K_BACKWARD, c.s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
-                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr, c.ld);
+                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr, c.ld, tpw);
     return hip_ok();
 }
 
@@ -887,7 +896,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     TRY(run_cloud_min<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     int rc = CONV3P_ERR_UNSUPPORTED;
-    int nslots = (int)grid_of(make_blockmap(d));
+    int nslots = (int)grid_of(make_blockmap_bwd(d));
     T *region = defer ? defer->region : nullptr;
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input, region);
@@ -1050,6 +1059,22 @@ int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B,
         if (hipEventRecord(ev[nl], after) != hipSuccess || hipStreamWaitEvent(s, ev[nl], 0) != hipSuccess)
             return CONV3P_ERR_LAUNCH;
     }
+    static const bool batched = std::getenv("CONV3P_STACK_MULTI") != nullptr;   // developer: all strides in one search launch
+    if (batched && nl <= kMaxJobs) {
+        int32_t strides[kMaxJobs * 3];
+        int k = 0;
+        for (int l = 0; l < nl; ++l) {
+            bool dup = false;
+            for (int m = 0; m < k; ++m)
+                dup |= strides[3 * m] == sd->strides[l][0] && strides[3 * m + 1] == sd->strides[l][1] && strides[3 * m + 2] == sd->strides[l][2];
+            if (!dup) { strides[3 * k] = sd->strides[l][0]; strides[3 * k + 1] = sd->strides[l][1]; strides[3 * k + 2] = sd->strides[l][2]; ++k; }
+        }
+        const Where wh = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
+                                    cfg->max_Cin, cfg->max_Cout, 0);
+        TRY(prepare_multi_impl<T>(points, strides, k, voxel, B, N, sd->fz, sd->fy, sd->fx, wh, s));
+        for (int l = 0; l < nl; ++l)
+            if (hipEventRecord(ev[l], s) != hipSuccess) return CONV3P_ERR_LAUNCH;
+    } else
     for (int l = 0; l < nl; ++l) {
         conv3p_cache_config c2 = *cfg;
         c2.flags = l > 0 ? CONV3P_CACHE_POINTS_UNCHANGED : 0;
