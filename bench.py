@@ -133,7 +133,9 @@ def cpu_baseline(points_np, feats_np, st, ups_np, budget_s=12.0):
     filters = [f.detach().cpu().numpy() for f in st.filters]
     have_ref = oracle.ref_compute("atrous_omp") is not None
     if have_ref:
-        cores = oracle.reference_threads()         # Conv3pGradOp forces hardware_concurrency() threads (.cpp:611-619)
+        # Conv3pGradOp forces hardware_concurrency() threads (.cpp:611-619) and both ops parallelise over the batch
+        # only (.cpp:453-456, :620-622): at most B threads ever have work
+        cores = max(1, min(points_np.shape[0], oracle.reference_threads()))
         fwd = lambda P, x, w, s: oracle.reference_forward(P, x, w, s, stack.VOXEL, kind="atrous_omp")
         bwd = lambda g, P, x, w, s: oracle.reference_backward(g, P, x, w, s, stack.VOXEL, kind="atrous_omp")
         kind = "reference"
@@ -157,6 +159,7 @@ def cpu_baseline(points_np, feats_np, st, ups_np, budget_s=12.0):
     what = ("the reference's own batch loops (tf_conv3p_atrous.cpp:451-504, :608-716 compiled in place, "
             "-O3 -fopenmp -DCONV_OPENMP)") if have_ref else "the oracle's C restatement"
     base = {"value": round(value, 4), "unit": "Mpoints/s", "cores": cores, "kind": kind,
+            "host_threads": oracle.reference_threads() if have_ref else cores,
             "sample": "%d repetitions of the full workload (B=%d, N=%d, 4-layer stack fwd+bwd) through %s, OpenMP "
                       "over the batch, %.1f s of CPU time" % (reps, points_np.shape[0], points_np.shape[1], what,
                                                               t_total)}
@@ -240,6 +243,34 @@ def cfg5_report(lib, dev, steps=5, warmup=2):
                          "note": "useful (dense-equivalent) flops; the matrix instructions ISSUED are more (selection "
                                  "products, tile padding) -- see profiles/ for SQ_INSTS_MFMA"},
             "kernel_ms_per_step": {k: round(v[1] / 2, 4) for k, v in kinds.items()}}
+
+
+def head_report(lib, dev, steps=20, warmup=3):
+    """The classification model's dense head at model size (pointcnn2_acsd.py:69-75): fc1 73 728 x 512 + fc2, forward
+    and backward, B=32 -- bound by one read (forward) / one read + one write (backward) of the 151 MB fc1 matrix."""
+    from pointwise_amd import head
+    B, N = B_PER_GPU, N_POINTS
+    hd = head.ClassificationHead(N, num_class=40, device=dev, seed=5)
+    feat = torch.randn((B, N, 36), device=dev)
+    labels = torch.randint(0, 40, (B,), device=dev)
+    mask = (torch.rand((B, 512), device=dev) < 0.5).float()
+    def fwd():
+        return hd.forward(feat, training=True, keep_mask=mask)
+    def both():
+        logits = fwd()
+        _, dlogits = hd.loss(logits, labels)
+        hd.backward(dlogits)
+    tf_ = timed(dev, fwd, steps, warmup)
+    tb_ = timed(dev, both, steps, warmup)
+    wbytes = hd.W1.numel() * 4
+    out = {"workload": "classification head: view (32, 73728) -> fc 512 selu -> dropout_selu -> fc 40 selu, softmax "
+                       "cross-entropy, forward+backward (fc1 weights 151 MB)",
+           "forward_ms": round(tf_ * 1e3, 4), "forward_backward_ms": round(tb_ * 1e3, 4),
+           "roofline": {"bound": "hbm", "scope": "forward+backward", "achieved": round(3 * wbytes / tb_ / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(3 * wbytes / tb_ / 1e9 / HBM_PEAK_GBS, 4),
+                        "bytes": 3 * wbytes, "note": "algorithmic bytes = fc1 read (forward) + fc1 read + dW1 write (backward)"}}
+    del hd
+    return out
 
 
 # ------------------------------------------------------------------------------------------- launch plumbing
@@ -422,7 +453,8 @@ def main():
             out["stateless_ms_per_step"] = round(dt_plain * 1e3, 4)
             out["stateless_value"] = round(total_pts / dt_plain / 1e6, 3)
             del st_plain
-            out["other_configs"] = {"cfg4": cfg4_report(lib, dev), "cfg5_shard": cfg5_report(lib, dev)}
+            out["other_configs"] = {"cfg4": cfg4_report(lib, dev), "cfg5_shard": cfg5_report(lib, dev),
+                                    "classification_head": head_report(lib, dev)}
         if world == 1 and not args.no_cpu:
             base, cfg1, ref = cpu_baseline(P, P.copy(), st, ups_np)
             out["cpu_baseline"] = base

@@ -151,15 +151,9 @@ BlockMap make_blockmap(const Dims &d)
     return m;
 }
 inline unsigned grid_of(const BlockMap &m) { return 8u * (unsigned)m.rounds * (unsigned)m.blocks_per_cloud; }
-// register-path backward: kBwdTiles consecutive query tiles per workgroup (one filter staging, one grad_filter
-// partial; for cfg2 the 512 workgroups are exactly what is resident at two per CU)
-constexpr int kBwdTiles = 1;   // measured: 2 tiles per workgroup (half the partials, one resident round) is SLOWER, 0.247 -> 0.306 ms/step -- the kernel is latency-bound per workgroup and wants as many tiles in flight as fit
-BlockMap make_blockmap_bwd(const Dims &d)
-{
-    BlockMap m = make_blockmap(d);
-    m.blocks_per_cloud = (d.ntiles + kBwdTiles - 1) / kBwdTiles;
-    return m;
-}
+// (Tried and dropped: two consecutive query tiles per backward workgroup -- half the grad_filter partials, one resident
+// round of 512 workgroups -- 0.247 -> 0.306 ms/step: the kernel is latency-bound per workgroup and wants as many tiles
+// in flight as fit; and handling the taps in 2-3 ranges to shrink G and fit a third workgroup per CU -- 0.247 -> 0.385.)
 
 // ----------------------------------------------------------------------------- buffer layout
 // One layout serves both the per-call workspace (1 slot, rebuilt every call) and the persistent
@@ -451,20 +445,20 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
-    // LDS: tapmap | max(G [F*CO][65], reduce buffer [4][CI][64]) | qorig | rinv | Wt | X tile | SoA
-    const size_t tail = (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)64 * CI * sizeof(T)) : 0) + a16((size_t)kWavesPerBlock * 192 * 4);
-    const size_t gsz = (size_t)st.ntap * CO * kCntStride, rsz = (size_t)kWavesPerBlock * CI * 64;
-    const size_t lds = lds_common(st) + (CI > 0 ? a16((gsz > rsz ? gsz : rsz) * sizeof(T)) + a16(256 * sizeof(T)) : 0) + 256 + tail;
+    // reduce buffer [4][CI][64] aliases { Wt | X tile | SoA }
+    size_t tail = (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)64 * CI * sizeof(T)) : 0) + a16((size_t)kWavesPerBlock * 192 * 4);
+    const size_t red = CI > 0 ? a16((size_t)kWavesPerBlock * CI * 64 * sizeof(T)) : 0;
+    if (tail < red) tail = red;
+    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * CO * kCntStride * sizeof(T)) + a16(256 * sizeof(T)) : 0) + 256 + tail;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
-    const int tpw = (CI > 0 && only_flagged == nullptr) ? kBwdTiles : 1;
-    const BlockMap bm = tpw > 1 ? make_blockmap_bwd(d) : make_blockmap(d);
+    const BlockMap bm = make_blockmap(d);
     Scope sc(K_BACKWARD, c.s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
-                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr, c.ld, tpw);
+                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr, c.ld);
     return hip_ok();
 }
 
@@ -896,7 +890,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     TRY(run_cloud_min<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
     int rc = CONV3P_ERR_UNSUPPORTED;
-    int nslots = (int)grid_of(make_blockmap_bwd(d));
+    int nslots = (int)grid_of(make_blockmap(d));
     T *region = defer ? defer->region : nullptr;
 #define X(ci, co)                                                                                    \
     if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input, region);
@@ -1041,7 +1035,7 @@ inline int stack_layers(const conv3p_stack_desc *sd) { return sd->n_hidden + (sd
 // geometry of every layer on `s`, ordered after `after`; one event per layer in the cache's host record
 template <typename T>
 int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B, int N, void *cache, size_t cache_bytes,
-                   const conv3p_cache_config *cfg, hipStream_t s, hipStream_t after, bool differs)
+                   const conv3p_cache_config *cfg, hipStream_t s, hipStream_t after, bool differs, bool one_launch)
 {
     const int nl = stack_layers(sd);
     std::vector<hipEvent_t> ev;
@@ -1059,8 +1053,11 @@ int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B,
         if (hipEventRecord(ev[nl], after) != hipSuccess || hipStreamWaitEvent(s, ev[nl], 0) != hipSuccess)
             return CONV3P_ERR_LAUNCH;
     }
-    static const bool batched = std::getenv("CONV3P_STACK_MULTI") != nullptr;   // developer: all strides in one search launch
-    if (batched && nl <= kMaxJobs) {
+    // one_launch (prefetch of the NEXT batch: nobody waits for the first layer's lists): all strides in ONE search
+    // launch, whose light tiles fill in behind another stride's heavy ones (0.534 -> 0.527 ms/step on cfg2);
+    // otherwise one launch and one event per layer, so that layer 0 can start as soon as its lists exist
+    static const bool no_batch = std::getenv("CONV3P_STACK_NO_MULTI") != nullptr;   // developer A/B switch
+    if (one_launch && !no_batch && nl <= kMaxJobs) {
         int32_t strides[kMaxJobs * 3];
         int k = 0;
         for (int l = 0; l < nl; ++l) {
@@ -1098,7 +1095,7 @@ int stack_prefetch_impl(const conv3p_stack_desc *sd, const T *points, T voxel, i
     if ((size_t)B * N == 0) return CONV3P_OK;
     if (!points) return CONV3P_ERR_INVALID_ARGUMENT;
     return stack_geometry<T>(sd, points, voxel, B, N, cache, cache_bytes, cfg, static_cast<hipStream_t>(stream),
-                             static_cast<hipStream_t>(after_stream), after_stream != stream);
+                             static_cast<hipStream_t>(after_stream), after_stream != stream, /*one_launch=*/true);
 }
 
 template <typename T>
@@ -1122,7 +1119,8 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
         if (it != g_caches.end()) it->second.pending_points = nullptr;
     }
     if (!events && side_stream != nullptr && side_stream != stream) {
-        TRY(stack_geometry<T>(sd, points, voxel, B, N, cache, cache_bytes, cfg, static_cast<hipStream_t>(side_stream), main, true));
+        TRY(stack_geometry<T>(sd, points, voxel, B, N, cache, cache_bytes, cfg, static_cast<hipStream_t>(side_stream), main, true,
+                              /*one_launch=*/false));
         std::lock_guard<std::mutex> lk(g_cache_mu);
         g_caches[cache].pending_points = nullptr;
         events = true;

@@ -892,9 +892,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     int gen_slots,                           // generic path: number of grad_filter partial slots the workgroups
                                              // spread their atomics over (slot = workgroup % gen_slots)
     const T *__restrict__ cmin,              // per-cloud grid origin (window-mode stencils, overflow path only)
-    RowLd ld,
-    int tpw)                                 // query tiles per workgroup (small path: consecutive tiles of a cloud share
-                                             // the filter staging and ONE grad_filter partial; bm counts groups of tpw)
+    RowLd ld)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -904,16 +902,13 @@ __global__ __launch_bounds__(256) void backward_kernel(
     size_t off = align16((size_t)3 * st.maxfull * 2);
     const size_t nw = (size_t)st.ntap * cin * cout;
     const int nrows = st.ntap * cout;
-    T *G = reinterpret_cast<T *>(smem + off);         // G[row][65]; after phases B / C: the dX reduce buffer [4][CIN][64]
-    if (kSmall) {   // room for G and for the reduce buffer that takes its place (small filters: the buffer is larger)
-        const size_t gsz = (size_t)nrows * kCntStride, rsz = (size_t)kWavesPerBlock * cin * 64;
-        off += align16((gsz > rsz ? gsz : rsz) * sizeof(T));
-    }
+    T *G = reinterpret_cast<T *>(smem + off);         // G[row][65]
+    if (kSmall) off += align16((size_t)nrows * kCntStride * sizeof(T));
     int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
     off += 256;
     T *rinv = reinterpret_cast<T *>(smem + off);      // rinv[n] = 1 / (T)n for n < 256 (the IEEE quotient): one LDS read
     if (kSmall) off += align16(256 * sizeof(T));      //   per pair instead of a division; larger populations divide
-    T *red = G;                                       // [4][CIN][64]
+    T *red = reinterpret_cast<T *>(smem + off);       // [4][CIN][64]: ALIASES wt | xt | soa (used after them)
     T *wt = reinterpret_cast<T *>(smem + off);        // Wt[row][k], row = f*COUT + c
     if (kSmall) off += align16(nw * sizeof(T));
     T *xt = reinterpret_cast<T *>(smem + off);        // X tile [64][CIN]
@@ -941,21 +936,16 @@ __global__ __launch_bounds__(256) void backward_kernel(
             }
         }
         rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;   // [0] = inf, never read (populations of 0 are skipped)
+        // G = 0, 16 bytes per store (G is 16-byte aligned, its length is padded to 4 by the LDS carve-up)
+        {
+            float4 *G4 = reinterpret_cast<float4 *>(G);
+            const int n4 = (int)((nrows * kCntStride * sizeof(T) + 15) / 16);
+            for (int e = threadIdx.x; e < n4; e += blockDim.x) G4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 
-    int b, blk;
-    const bool wg_live = block_to_cloud(bm, b, blk);   // uniform for the workgroup
-  for (int rep = 0; rep < tpw; ++rep) {
-    const int qt = blk * tpw + rep;
-    bool live = wg_live && qt < ntiles;
-    if (rep > 0 && !live) break;                       // (uniform) nothing left for this workgroup
-    if constexpr (kSmall) {
-        if (rep > 0) __syncthreads();                  // previous tile's reduce buffer (in G) consumed
-        // G = 0, 16 bytes per store (G is 16-byte aligned, its length is padded to 4 by the LDS carve-up)
-        float4 *G4 = reinterpret_cast<float4 *>(G);
-        const int n4 = (int)((nrows * kCntStride * sizeof(T) + 15) / 16);
-        for (int e = threadIdx.x; e < n4; e += blockDim.x) G4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    int b, qt;
+    bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
     if (live && only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) live = false;   // deep path did it
     const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
     PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
@@ -1166,10 +1156,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
             }
             const int f = row / COUT, c = row - f * COUT;
 #pragma unroll
-            for (int k = 0; k < CIN; ++k) {
-                T *sp = slot + ((size_t)f * CIN + k) * COUT + c;   // one partial per workgroup: later tiles add (same thread)
-                *sp = rep == 0 ? acc[k] : *sp + acc[k];
-            }
+            for (int k = 0; k < CIN; ++k) slot[((size_t)f * CIN + k) * COUT + c] = acc[k];
         }
         // ---- phase C: dX rows.  lane = centre j, waves split the rows.
         T dx[CIN];
@@ -1199,7 +1186,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
             }
         }
-        __syncthreads();   // red aliases G: every thread is done reading it (phases B and C)
+        __syncthreads();   // red aliases wt / xt: every wave is done reading them
 #pragma unroll
         for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
         __syncthreads();
@@ -1216,7 +1203,6 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 }
             }
     }
-  }   // tiles of this workgroup
 }
 
 // grad_filter[e] = sum over partial slots, fixed order (slot index ascending within a wave's
