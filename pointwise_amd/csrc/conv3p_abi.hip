@@ -242,6 +242,8 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
 
 inline bool small_shape(int elem, int cin, int cout)
 {
+    static const bool skip = std::getenv("CONV3P_SKIP_SMALL") != nullptr;   // developer: time the other paths on the models' shapes
+    if (skip) return false;
     (void)elem;   // fp32 and fp64 (the kernels are templates on T; shapes whose LDS does not fit fall back at launch)
 #define X(ci, co) if (cin == ci && cout == co) return true;
     CONV3P_SMALL_SHAPES(X)
@@ -763,7 +765,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     TRY(run_cloud_min<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
 #define X(ci, co)                                                                                    \
-    if (Cin == ci && Cout == co) {                                                                   \
+    if (Cin == ci && Cout == co && small_shape((int)sizeof(T), Cin, Cout)) {                         \
         int rc = launch_forward<T, ci, co>(c, input, filter, output);                                \
         if (rc != CONV3P_ERR_UNSUPPORTED) return rc;                                                 \
     }
@@ -893,7 +895,8 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     int nslots = (int)grid_of(make_blockmap(d));
     T *region = defer ? defer->region : nullptr;
 #define X(ci, co)                                                                                    \
-    if (Cin == ci && Cout == co) rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input, region);
+    if (Cin == ci && Cout == co && small_shape((int)sizeof(T), Cin, Cout))                           \
+        rc = launch_backward<T, ci, co>(c, grad_out, input, filter, grad_input, region);
     CONV3P_SMALL_SHAPES(X)
 #undef X
     if (defer && rc == CONV3P_OK) {

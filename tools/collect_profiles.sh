@@ -15,12 +15,12 @@ STEPS=20; WARM=5
 
 python $ROOT/bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o t -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu > $OUT/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o t -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-extra > $OUT/${TAG}_trace.log 2>&1
 python $ROOT/tools/pmc_query.py $OUT/${TAG}_trace/t_results.db > $OUT/${TAG}_kernel_stats.txt 2>&1
 
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"; do
   N=$(echo $C | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$N -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu > $OUT/${TAG}_pmc_$N.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_pmc_$N -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu --no-extra > $OUT/${TAG}_pmc_$N.log 2>&1
   python $ROOT/tools/pmc_query.py $OUT/${TAG}_pmc_$N/p_results.db conv3p > $OUT/${TAG}_pmc_$N.txt 2>&1
 done
 python $ROOT/tools/traffic_json.py $OUT/${TAG}_pmc_FETCH_SIZE/p_results.db $OUT/${TAG}_pmc_WRITE_SIZE/p_results.db > $OUT/${TAG}_traffic.json
@@ -30,9 +30,13 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_deep_trace -o t -- python $ROOT/
 python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_trace/t_results.db deep > $OUT/${TAG}_deep_kernel_stats.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_deep_pmc -o p -- python $ROOT/tools/deep_time.py > $OUT/${TAG}_deep_pmc.log 2>&1
 python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_pmc/p_results.db deep > $OUT/${TAG}_deep_pmc_MFMA.txt 2>&1
+# 4b. the classification head's FC kernels (fc1 73 728 x 512) and the serial (no side stream) kernel durations
+python $ROOT/tools/head_time.py > $OUT/${TAG}_head_time.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_serial_trace -o t -- python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-extra --serial > $OUT/${TAG}_serial_trace.log 2>&1
+python $ROOT/tools/pmc_query.py $OUT/${TAG}_serial_trace/t_results.db > $OUT/${TAG}_kernel_stats_serial.txt 2>&1
 # 5. other shapes / dtypes: the models' stacks at cfg2 and cfg4, fp64 on the register path, the generic kernels
 python $ROOT/tools/stack_time.py > $OUT/${TAG}_stack_time.txt 2>&1
 python $ROOT/tools/f64_time.py > $OUT/${TAG}_f64_time.txt 2>&1
 python $ROOT/tools/generic_time.py > $OUT/${TAG}_generic_time.txt 2>&1
-rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_*/ $OUT/${TAG}_deep_trace $OUT/${TAG}_deep_pmc   # keep the text summaries, drop the databases
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_serial_trace $OUT/${TAG}_pmc_*/ $OUT/${TAG}_deep_trace $OUT/${TAG}_deep_pmc   # keep the text summaries, drop the databases
 tail -c 1500 $OUT/${TAG}_bench.json; echo; head -14 $OUT/${TAG}_kernel_stats.txt; cat $OUT/${TAG}_traffic.json
