@@ -240,8 +240,9 @@ def cfg5_report(lib, dev, steps=5, warmup=2):
             "roofline": {"bound": "mfma", "scope": "whole step", "achieved": round(achieved, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                          "flops_per_point": 3 * 2 * 27 * ci * co,
-                         "note": "useful (dense-equivalent) flops; the matrix instructions ISSUED are more (selection "
-                                 "products, tile padding) -- see profiles/ for SQ_INSTS_MFMA"},
+                         "note": "useful (dense-equivalent) flops = 3 x 2*27*Cin*Cout per point; the matrix "
+                                 "instructions ISSUED are fewer (only populated (tile, tap) products run) -- see "
+                                 "profiles/ for SQ_INSTS_MFMA"},
             "kernel_ms_per_step": {k: round(v[1] / 2, 4) for k, v in kinds.items()}}
 
 

@@ -106,12 +106,18 @@ class Conv3pStack:
         return ctypes.c_float(v) if self.dtype == torch.float32 else ctypes.c_double(v)
 
     def _free_cache_index(self):
-        """A cache that neither serves the batch between forward() and backward() nor holds a pending prefetch."""
-        for idx in (1 - self._which, self._which):
+        """The cache a new prefetch may use: never the one serving the batch between forward() and backward(); a
+        cache that holds a prefetch nobody consumed yet is taken only when nothing else is free (that prefetch
+        is then simply lost: its batch will search for itself)."""
+        order = (1 - self._which, self._which)
+        for idx in order:
             if idx != self._inflight and idx not in self._pending:
                 return idx
-        raise op.Conv3pRuntimeError("prefetch(): both neighbour caches are busy (one batch in flight, one prefetch "
-                                    "pending) -- call forward() on the prefetched batch first")
+        for idx in order:
+            if idx != self._inflight:
+                self._pending.pop(idx, None)
+                return idx
+        raise op.Conv3pRuntimeError("prefetch(): no neighbour cache is free")   # unreachable with two caches
 
     def _c_prefetch(self, points):
         for idx, t in self._pending.items():
