@@ -561,7 +561,7 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
 {
     const Dims &d = c.d;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = a16((size_t)(KD < 256 ? 256 / KD : 1) * 64 * (KD + 1) * 4) + 3 * (size_t)kDeepBatch * 4 + 256 + 1024;
+    const size_t lds = a16((size_t)(KD < 256 ? 256 / KD : 1) * 64 * (KD + 1) * 4) + 4 * (size_t)kDeepBatch * 4 + 256 + 1024;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_DEEP_GEMM, c.s);

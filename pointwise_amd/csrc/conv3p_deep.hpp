@@ -5,13 +5,10 @@
 //     dX[j,:]   = sum_f' G_f'[j,:] . W[f']^T       G_f'[j,:] = sum_{ii: bwd tap f'} dY[ii,:] / count[ii,f']
 //     dW[f']    = sum_pairs(f')  x[j,:]^T . (dY[ii,:] / count[ii,f'])
 // (same sums as tf_conv3p_atrous.cpp:480-494 and :682-698, re-associated; inside the fp32 tolerance).
-// Everything, including the per-centre reductions M_f / G_f', runs on v_mfma_f32_32x32x2_f32 (exact fp32, an
-// fmaf chain per output, 64 FLOP/clk/SIMD):
+// The contractions with the filter run on v_mfma_f32_32x32x2_f32 (exact fp32, an fmaf chain per output,
+// 64 FLOP/clk/SIMD); the per-centre reductions M_f / G_f' are segmented sums on the vector ALUs:
 //   * a tile's records are put in tap-major order once (deep_order_kernel, a stable counting sort);
-//   * per tap, the neighbour rows of 32 records at a time are COPIED into LDS (coalesced, whole rows, the next
-//     block's loads in flight under the current block's MFMAs) -- no per-centre serial gather chains;
-//   * M_f = S_f . rows, where S_f[centre][record] = 1/count if the record belongs to the centre, else 0, is built
-//     in the A-operand registers on the fly (one compare + select per MFMA step);
+//   * per tap, M_f is a branch-free segmented sum over the tap's run of records (deep_gemm_kernel stage 1);
 //   * M_f . W[f] follows from LDS, the W[f] operand streamed from L2 sixteen k-rows ahead;
 //   * dW[f'] = sum over tiles of X_tile^T . G_f'[tile]: the grad_input kernel leaves every G_f' tile ([64][Cout], the
 //     per-centre reduction it computes anyway) in a scratch buffer, and the grad_filter kernel is a plain
@@ -234,10 +231,10 @@ __device__ __forceinline__ int qorig_early(const PointRec<float> *__restrict__ p
 }
 
 // metadata of up to kDeepBatch records of one (tile, tap) run -> LDS (thread = record: one coalesced load).
-// mqr[t] = {centre lane, bits of 1/count}; entries past the run: row 0 (never loaded), centre 64 (matches no
-// lane; row 64 of deep_dw_kernel's X tile is all zero), weight 0.
-__device__ __forceinline__ void deep_fetch_meta(const uint2 *__restrict__ meta, uint32_t e0, uint32_t e1,
-                                                uint32_t *mcand, uint2 *mqr)
+// mrec[t] = {first element of the neighbour's row (index * row length), centre lane, bits of 1/count, -}: one
+// 16-byte LDS read per record in stage 1.  Entries past the run: row 0, centre 64 (matches no lane), weight 0.
+__device__ __forceinline__ void deep_fetch_meta(const uint2 *__restrict__ meta, uint32_t e0, uint32_t e1, uint32_t kreal,
+                                                uint4 *mrec)
 {
     const uint32_t t = threadIdx.x;
     uint32_t cand = 0, q = 64;
@@ -250,8 +247,7 @@ __device__ __forceinline__ void deep_fetch_meta(const uint2 *__restrict__ meta, 
         q = m.y & 0xFFu;
         rcp = 1.0f / (float)(m.y >> 8);       // the IEEE quotient, as the register path computes it
     }
-    mcand[t] = cand;
-    mqr[t] = make_uint2(q, __builtin_bit_cast(uint32_t, rcp));
+    mrec[t] = make_uint4(cand * kreal, q, __builtin_bit_cast(uint32_t, rcp), 0u);   // < 2^31: N * kreal floats per cloud
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,11 +255,11 @@ __device__ __forceinline__ void deep_fetch_meta(const uint2 *__restrict__ meta, 
 //   BWD = false : forward.    src = input    (rows of KDIM = Cin),  order/weights of the forward taps, Bm = filter
 //   BWD = true  : grad_input. src = grad_out (rows of KDIM = Cout), backward taps, Bm = filter^T ([F][Cout][Cin])
 // One workgroup (4 waves) per query tile; per tap:
-//   stage 1  M_f = S_f . rows           32 records per block: rows copied to LDS [32][KDIM+32], the 2 x KDIM/32
-//                                        blocks of M_f dealt to the waves, accumulated in registers over the blocks
-//   stage 2  out += M_f . Bm[f]          M_f through LDS [64][KDIM+1] (aliases the row buffer), the 2 x NDIM/32
-//                                        output blocks dealt to the waves, accumulators in registers across all taps
-// LDS: { M_f [64][KDIM+1] | rows [32][KDIM+32] } | meta (cand, centre, 1/count) [256] x 3 | qorig [64]
+//   stage 1  M_f[centre] = segmented sum of the tap's neighbour rows / count on the vector ALUs (thread = column,
+//            rows straight from global memory, 2 x 16 loads in flight per thread) -> LDS [kGroups][64][KDIM+1]
+//   stage 2  out += M_f . Bm[f]          the 2 x NDIM/32 output blocks dealt to the waves, accumulators in registers
+//                                        across all taps, B operand streamed from L2
+// LDS: M_f [kGroups][64][KDIM+1] | meta {row start, centre, 1/count, -} [256] | qorig [64] | scrap [256]
 // ---------------------------------------------------------------------------------------------
 template <int KDIM, int NDIM, bool BWD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_WAVES))) void deep_gemm_kernel(const PointRec<float> *__restrict__ pts,
@@ -296,9 +292,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);           // M_f [kGroups][64][LDA] (partial sums, added on read)
     size_t off = align16((size_t)kGroups * 64 * LDA * 4);
-    uint2 *mqr = reinterpret_cast<uint2 *>(smem + off);
-    uint32_t *mcand = reinterpret_cast<uint32_t *>(mqr + kDeepBatch);
-    int32_t *qorig = reinterpret_cast<int32_t *>(mcand + kDeepBatch);
+    uint4 *mrec = reinterpret_cast<uint4 *>(smem + off);
+    int32_t *qorig = reinterpret_cast<int32_t *>(mrec + kDeepBatch);
     float *scrap = reinterpret_cast<float *>(qorig + 64);   // [256] write-only (stage 1's predicated-off stores)
 
     // workgroup -> tile: XCD (blockIdx.x & 7, as in BlockMap) and position in that XCD's longest-first order
@@ -376,27 +371,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             // added when stage 2 reads them: every thread has a load to issue at every step.
             const int col = (int)threadIdx.x % KDIM, grp = (int)threadIdx.x / KDIM;
             const bool col_ok = col < kreal;
+            const int colc = col_ok ? col : 0;
             float *Ag = A + grp * 64 * LDA + col;
             float *dummy = scrap + threadIdx.x;              // where the stores of steps past the run's end go
             float sum = 0.0f;
             uint32_t prev = 64;                              // centre of the running sum (64 = none)
             for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
                 if (eb != e0) __syncthreads();               // previous batch's metadata consumed
-                deep_fetch_meta(meta, eb, e1, mcand, mqr);
+                deep_fetch_meta(meta, eb, e1, (uint32_t)kreal, mrec);
                 __syncthreads();                             // (first batch: also orders the zeroing of A)
                 GDBG(0)
                 const uint32_t nrec = (CONV3P_ABLATE & 32768) ? 0u : min((uint32_t)kDeepBatch, e1 - eb);
                 constexpr int kU = 16;                       // records per thread and step; two steps in flight
+                // Every load of a step is UNCONDITIONAL (steps past the run's end re-read record 0, columns past the
+                // real row length re-read column 0; both are discarded by selects afterwards): with predicated loads
+                // hipcc wraps each one in its own exec-mask branch -- LDS read, wait, address, load, sixteen times in
+                // series -- and can no longer count the loads in flight, so every step drained the queue.
                 auto fetch = [&](uint32_t p0, float (&v)[kU], float (&w)[kU], uint32_t (&q)[kU]) {
+                    uint4 m[kU];
 #pragma unroll
                     for (int u = 0; u < kU; ++u) {
                         const uint32_t p = p0 + (uint32_t)(u * kGroups + grp);
-                        const bool in = p < nrec;
-                        const uint2 m = mqr[in ? p : 0];
-                        q[u] = in ? m.x : 64u;
-                        w[u] = __builtin_bit_cast(float, m.y);
-                        v[u] = 0.0f;
-                        if (in && col_ok) v[u] = src_cloud[(size_t)mcand[in ? p : 0] * kreal + col];
+                        m[u] = mrec[p < nrec ? p : 0u];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // all 16 LDS reads issued before the first one is waited for
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const uint32_t p = p0 + (uint32_t)(u * kGroups + grp);
+                        q[u] = p < nrec ? m[u].y : 64u;
+                        w[u] = __builtin_bit_cast(float, m[u].z);
+                        v[u] = src_cloud[m[u].x + (uint32_t)colc];
                     }
                 };
                 auto consume = [&](const float (&v)[kU], const float (&w)[kU], const uint32_t (&q)[kU]) {
@@ -404,7 +408,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                     for (int u = 0; u < kU; ++u) {
                         const bool in = q[u] != 64u;
                         badsum += v[u] - v[u];               // 0 for finite values, NaN otherwise (see the epilogue)
-                        const float t = q[u] == prev ? __builtin_fmaf(v[u], w[u], sum) : v[u] * w[u];
+                        const float x = col_ok ? v[u] : 0.0f;
+                        const float t = q[u] == prev ? __builtin_fmaf(x, w[u], sum) : x * w[u];
                         sum = in ? t : sum;
                         prev = in ? q[u] : prev;
                         float *dst = in ? Ag + q[u] * LDA : dummy;

@@ -462,13 +462,13 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
             for (int i = wave + lane * kWavesPerBlock; i < 64 && base + i < ct1; i += 64 * kWavesPerBlock)
                 tot[base + i - ct0] = 0;
             uint64_t todo = live & (0x1111111111111111ull << wave);
-            PointRec<T> rec;
-            if (todo) rec = cloud_pts[(size_t)(base + __builtin_ctzll(todo)) * kTile + lane];
+            // (prefetches are unconditional: with nothing left to do they re-read the current tile)
+            PointRec<T> rec = cloud_pts[(size_t)(base + (todo ? __builtin_ctzll(todo) : 0)) * kTile + lane];
             while (todo) {
                 const int ct = base + __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const uint64_t quads = stage_tile(soa, rec, st, q);
-                if (todo) rec = cloud_pts[(size_t)(base + __builtin_ctzll(todo)) * kTile + lane];   // prefetch
+                rec = cloud_pts[(size_t)(todo ? base + __builtin_ctzll(todo) : ct) * kTile + lane];   // prefetch
                 __builtin_amdgcn_wave_barrier();
                 uint32_t m0, m1;
                 if (CONV3P_ABLATE & 32) { m0 = m1 = 0; } else scan_tile(soa, q, st, quads, m0, m1);
@@ -713,8 +713,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const int32_t *tc = tcount + ((size_t)b * ntiles + qt) * st.ntap * kTile;
 #pragma unroll
         for (int u = 0; u < kTcPer; ++u) {
+            // unconditional load from a clamped index (a predicated load gets its own exec-mask branch and a full
+            // vmcnt(0) wait from hipcc: eight memory latencies in series instead of one)
             const int e = (int)threadIdx.x + 256 * u;
-            tcv[u] = e < st.ntap * kTile ? tc[e] : 1;
+            tcv[u] = tc[e < st.ntap * kTile ? e : 0];
         }
     }
     if (kSmall) {
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         for (uint32_t e0 = threadIdx.x; e0 < (uint32_t)nw; e0 += 8 * 256) {
             T v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = e0 + u * 256 < (uint32_t)nw ? filter[e0 + u * 256] : (T)0;
+            for (int u = 0; u < 8; ++u) v[u] = filter[e0 + u * 256 < (uint32_t)nw ? e0 + u * 256 : 0u];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (e0 + u * 256 < (uint32_t)nw) {
@@ -802,15 +804,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 // read 4 consecutive pair records per step (64 contiguous bytes)
                 const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                 const PairEntry *pe = pairs + sg.x;
-                PairEntry cur = pe[(uint32_t)sub < sg.y ? sub : 0];
-                for (uint32_t i = sub; __any(i < sg.y); i += 4) {
-                    const uint32_t nx = i + 4;
-                    const PairEntry nxt = pe[nx < sg.y ? nx : 0];   // prefetch the next record
-                    if (i < sg.y) {
-                        const uint32_t f = code_fwd(cur.code);
-                        if (f != kNoTap) accumulate(cur.cand, f, (uint32_t)cq, rcpt[f * kCntStride + cq]);
+                // Software pipeline over NS NAMED slots (the loop is unrolled by NS so that a slot is a fixed
+                // set of registers): the record of step k+2 and the neighbour row of step k+1 are in flight while
+                // step k runs its 81 FMAs.  Rotating the slots by register copies would make every step wait for
+                // the newest load (a copy reads its destination registers), i.e. no pipeline at all.  All loads are
+                // unconditional from clamped addresses, so hipcc can count the ones in flight.
+                // (NS = 2 for the widest rows, whose three copies would not fit the register file: the row is then
+                // loaded in the step that uses it, as before)
+                constexpr int NS = sizeof(T) * CIN <= 144 ? 3 : 2;
+                PairEntry rec[NS];
+                T xs[NS][CIN];
+                auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
+                auto ld_row = [&](int sl, uint32_t i) {
+                    const bool ok = i < sg.y && code_fwd(rec[sl].code) != kNoTap;
+                    RowLoader<T, CIN>::load(in_cloud + (size_t)(ok ? rec[sl].cand : 0u) * ld.in, xs[sl]);
+                };
+#pragma unroll
+                for (int sl = 0; sl < NS - 1; ++sl) rec[sl] = ld_rec(sub + 4 * sl);
+#pragma unroll
+                for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + 4 * sl);
+                uint32_t i = sub;
+                bool more = true;
+                while (more) {
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) {
+                        if (!__any(i < sg.y)) {
+                            more = false;
+                            break;
+                        }
+                        rec[(j + NS - 1) % NS] = ld_rec(i + 4 * (NS - 1));
+                        ld_row((j + NS - 2) % NS, i + 4 * (NS - 2));
+                        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of this step's arithmetic
+                        const uint32_t f = code_fwd(rec[j].code);
+                        if (i < sg.y && f != kNoTap) {
+                            const T rcp = rcpt[f * kCntStride + cq];
+                            const T *wf = w_lds + (size_t)f * WSTR;
+#pragma unroll
+                            for (int k = 0; k < CIN; ++k) {
+                                const T xk = xs[j][k] * rcp;                  // x / count, .cpp:492
+#pragma unroll
+                                for (int c = 0; c < COUT; ++c) acc[c] = fma_t(wf[k * COUT + c], xk, acc[c]);
+                            }
+                        }
+                        i += 4;
                     }
-                    cur = nxt;
                 }
             } else {
                 const uint2 sg = segs[tile_id * ngroups + g];
@@ -954,8 +991,10 @@ __global__ __launch_bounds__(256) void backward_kernel(
         qorig[lane] = me.idx;
         if (kSmall) {
             const T *xr = input + ((size_t)(live ? b : 0) * N + (me.idx < 0 ? 0 : me.idx)) * ld.in;
+            T xv[kSmall ? CIN : 1];
+            RowLoader<T, (kSmall ? CIN : 1)>::load(xr, xv);   // unconditional (padding lanes read row 0), then select
 #pragma unroll
-            for (int k = 0; k < (kSmall ? CIN : 1); ++k) xt[lane * cin + k] = me.idx >= 0 ? xr[k] : (T)0;
+            for (int k = 0; k < (kSmall ? CIN : 1); ++k) xt[lane * cin + k] = me.idx >= 0 ? xv[k] : (T)0;
         }
     }
     __syncthreads();
@@ -1014,96 +1053,107 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     // lower sub-lane goes first (fixed order), the other retries -> race-free, reproducible.
                     const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
                     const PairEntry *pe = pairs + sg.x;
-                    // software pipeline: record two steps ahead; dY row and the neighbour's population of the
-                    // backward tap (4-byte gather next to the row) one step ahead
                     auto live_rec = [&](const PairEntry &r, uint32_t i) {
                         return i < sg.y && code_fwd(r.code) != kNoTap && code_bwd(r.code) != kNoTap;
                     };
                     auto cnt_of = [&](const PairEntry &r, bool live) {
-                        if (CONV3P_ABLATE & 2048) return live ? 1 : 0;   // developer: timing without the gather
-                        return live ? cnt_cloud[(size_t)r.cand * st.ntap + code_bwd(r.code)] : 0;
+                        if (CONV3P_ABLATE & 2048) return 1;   // developer: timing without the gather
+                        // unconditional load from a clamped address + select: a predicated load sits in its own
+                        // exec-mask branch, after which hipcc waits for ALL loads in flight (vmcnt(0)) at the top of
+                        // every step and the software pipeline below is worth nothing
+                        // (no select on the result either -- hipcc would sink the load into the select's branch; a
+                        // dead slot reads element 0 and the caller masks with `live`)
+                        return cnt_cloud[live ? (size_t)r.cand * st.ntap + code_bwd(r.code) : (size_t)0];
                     };
-                    // (with 78 KB of LDS only two workgroups fit a CU, so the latency of the two gathers is hidden by
-                    // depth, not by occupancy: records run three steps ahead, rows and populations two)
-                    PairEntry cur = pe[(uint32_t)sub < sg.y ? sub : 0];
-                    PairEntry nxt = pe[(uint32_t)sub + 4 < sg.y ? sub + 4 : 0];
-                    PairEntry nx2 = pe[(uint32_t)sub + 8 < sg.y ? sub + 8 : 0];
-                    T val[COUT], nval[COUT];
-                    bool cur_live = live_rec(cur, sub), nxt_live = live_rec(nxt, sub + 4);
-                    int cur_cnt = cnt_of(cur, cur_live), nxt_cnt = cnt_of(nxt, nxt_live);
-                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(cur_live ? cur.cand : 0) * ld.dy, val);
-                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(nxt_live ? nxt.cand : 0) * ld.dy, nval);
+                    // With 78 KB of LDS only two workgroups fit a CU, so the latency of the gathers is hidden by depth,
+                    // not by occupancy: the record of step k+3 and the dY row + population of step k+2 are in flight
+                    // while step k runs.  Four NAMED slots, the loop unrolled by four: a slot is a fixed set of
+                    // registers.  (Rotating slots by register copies made every step wait for the newest load -- a
+                    // copy reads its destination -- so the "pipeline" drained the queue every step.)
+                    PairEntry rec[4];
+                    bool lv[4];
+                    int cn[4];
+                    T val[4][COUT];
+                    auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
+                    auto gather = [&](int sl, uint32_t i) {
+                        lv[sl] = live_rec(rec[sl], i);
+                        cn[sl] = cnt_of(rec[sl], lv[sl]);
+                        RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy, val[sl]);
+                    };
+                    rec[0] = ld_rec(sub);
+                    rec[1] = ld_rec(sub + 4);
+                    rec[2] = ld_rec(sub + 8);
+                    __builtin_amdgcn_sched_barrier(0);   // the three records are the oldest loads in flight on entry
+                    gather(0, sub);
+                    gather(1, sub + 4);
                     T ablate_sink = (T)0;
-                    for (uint32_t i = sub; __any(i < sg.y); i += 4) {
-                        const PairEntry nx3 = pe[i + 12 < sg.y ? i + 12 : 0];
-                        T n2val[COUT];
-                        const bool nx2_live = live_rec(nx2, i + 8);
-                        const int nx2_cnt = cnt_of(nx2, nx2_live);
-                        RowLoader<T, COUT>::load(dy_cloud + (size_t)(nx2_live ? nx2.cand : 0) * ld.dy, n2val);
-                        // false positive, hole, or empty tap (.cpp:679) -> contributes nothing
-                        bool pending = cur_live && cur_cnt != 0;
-                        const uint32_t fb = code_bwd(cur.code);
-                        if (pending) {
-                            const T rcpb = cur_cnt < 256 ? rinv[cur_cnt] : (T)1 / (T)cur_cnt;   // .cpp:692, :696
+                    uint32_t i = sub;
+                    bool more = true;
+                    while (more) {
 #pragma unroll
-                            for (int c = 0; c < COUT; ++c) val[c] *= rcpb;
-                        }
-                        if (CONV3P_ABLATE & 256) {
-                            if (pending) {
-#pragma unroll
-                                for (int c = 0; c < COUT; ++c) ablate_sink += val[c];
+                        for (int j = 0; j < 4; ++j) {
+                            if (!__any(i < sg.y)) {
+                                more = false;
+                                break;
                             }
-                            pending = false;
-                        }
-                        if (CONV3P_ABLATE & 512) {
+                            rec[(j + 3) & 3] = ld_rec(i + 12);
+                            gather((j + 2) & 3, i + 8);
+                            __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of this step's arithmetic
+                            // false positive, hole, or empty tap (.cpp:679) -> contributes nothing
+                            bool pending = lv[j] & (cn[j] != 0);
+                            const uint32_t fb = code_bwd(rec[j].code);
+                            T(&v)[COUT] = val[j];
+                            if (pending) {
+                                const T rcpb = cn[j] < 256 ? rinv[cn[j]] : (T)1 / (T)cn[j];   // .cpp:692, :696
+#pragma unroll
+                                for (int c = 0; c < COUT; ++c) v[c] *= rcpb;
+                            }
+                            if (CONV3P_ABLATE & 256) {
+                                if (pending) {
+#pragma unroll
+                                    for (int c = 0; c < COUT; ++c) ablate_sink += v[c];
+                                }
+                                pending = false;
+                            }
+                            if (CONV3P_ABLATE & 512) {
+                                if (pending) {
+                                    T *grow = G + ((size_t)fb * COUT) * kCntStride + cq;
+#pragma unroll
+                                    for (int c = 0; c < COUT; ++c)
+                                        __hip_atomic_fetch_add(&grow[c * kCntStride], v[c], __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                                }
+                                pending = false;
+                            }
+                            // Sub-lanes of one centre that target the same tap are merged first (fixed order:
+                            // partner distance 16, 32, 48 lanes; the lower sub-lane absorbs the higher one), so a
+                            // single race-free read-modify-write round follows.  Neighbouring candidates usually
+                            // share a tap, so without the merge this would take 2-3 rounds.
+#pragma unroll
+                            for (int step = 0; step < 3; ++step) {
+                                const uint32_t mine_fb = pending ? fb : kNoTap;
+                                uint32_t pfb;
+                                bool lower;
+                                if (step == 0) { pfb = lane_xor16(mine_fb); lower = (sub & 1) == 0; }
+                                else if (step == 1) { pfb = lane_xor32(mine_fb); lower = sub < 2; }
+                                else { pfb = lane_xor32(lane_xor16(mine_fb)); lower = sub < 2; }
+                                const bool same = pending && pfb == fb;
+                                if (__any(same)) {
+#pragma unroll
+                                    for (int c = 0; c < COUT; ++c) {
+                                        const T pv = step == 0 ? lane_xor16(v[c])
+                                                   : step == 1 ? lane_xor32(v[c]) : lane_xor32(lane_xor16(v[c]));
+                                        if (same && lower) v[c] += pv;
+                                    }
+                                    if (same && !lower) pending = false;
+                                }
+                            }
                             if (pending) {
                                 T *grow = G + ((size_t)fb * COUT) * kCntStride + cq;
 #pragma unroll
-                                for (int c = 0; c < COUT; ++c)
-                                    __hip_atomic_fetch_add(&grow[c * kCntStride], val[c], __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                                for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += v[c];
                             }
-                            pending = false;
-                        }
-                        // Sub-lanes of one centre that target the same tap are merged first (fixed order:
-                        // partner distance 16, 32, 48 lanes; the lower sub-lane absorbs the higher one), so a
-                        // single race-free read-modify-write round follows.  Neighbouring candidates usually
-                        // share a tap, so without the merge this would take 2-3 rounds.
-#pragma unroll
-                        for (int step = 0; step < 3; ++step) {
-                            const uint32_t mine_fb = pending ? fb : kNoTap;
-                            uint32_t pfb;
-                            bool lower;
-                            if (step == 0) { pfb = lane_xor16(mine_fb); lower = (sub & 1) == 0; }
-                            else if (step == 1) { pfb = lane_xor32(mine_fb); lower = sub < 2; }
-                            else { pfb = lane_xor32(lane_xor16(mine_fb)); lower = sub < 2; }
-                            const bool same = pending && pfb == fb;
-                            if (__any(same)) {
-#pragma unroll
-                                for (int c = 0; c < COUT; ++c) {
-                                    const T pv = step == 0 ? lane_xor16(val[c])
-                                               : step == 1 ? lane_xor32(val[c]) : lane_xor32(lane_xor16(val[c]));
-                                    if (same && lower) val[c] += pv;
-                                }
-                                if (same && !lower) pending = false;
-                            }
-                        }
-                        if (pending) {
-                            T *grow = G + ((size_t)fb * COUT) * kCntStride + cq;
-#pragma unroll
-                            for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += val[c];
-                        }
-                        cur = nxt;
-                        nxt = nx2;
-                        nx2 = nx3;
-                        cur_live = nxt_live;
-                        cur_cnt = nxt_cnt;
-                        nxt_live = nx2_live;
-                        nxt_cnt = nx2_cnt;
-#pragma unroll
-                        for (int c = 0; c < COUT; ++c) {
-                            val[c] = nval[c];
-                            nval[c] = n2val[c];
+                            i += 4;
                         }
                     }
                     if (CONV3P_ABLATE & 256) G[cq] += ablate_sink;
