@@ -502,6 +502,7 @@ struct DeepScratch {   // carved from the per-call scratch region
     uint2 *tap_meta;       // per pair slot, tap-major inside a tile: {neighbour, centre lane | population << 8}
     uint32_t *tap_off;     // [tiles][F+1]
     uint8_t *tile_flag;    // [tiles]
+    unsigned long long *pop_mask;   // [tiles] bit f: the tile has records of backward tap f (deep_order -> deep_plan)
     uint32_t *sched;       // [8][sched_cap] launch order of the tiles per XCD (deep_sched_kernel)
     int sched_cap;
     uint32_t *tap_total;   // [64] pairs per backward tap, then [1] number of work items  (deep_plan_kernel)
@@ -524,6 +525,7 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     s.tap_meta = reinterpret_cast<uint2 *>(take(pair_slots * 8));
     s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
+    s.pop_mask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * 8));
     s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
     s.sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
     s.tap_total = reinterpret_cast<uint32_t *>(take(65 * 4));
@@ -542,15 +544,15 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     const Dims &d = c.d;
     if (d.ntap > 64) return CONV3P_ERR_UNSUPPORTED;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = (size_t)18 * d.ntap * 4 + 256;
+    const size_t lds = (size_t)(2 + 4 * kOrderR) * d.ntap * 4 + 256;
     Scope sc(K_DEEP_ORDER, c.s);
     if (BWD) TRY(zero_async(ds.tap_total, 65 * 4, c.s));
     hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, c.L.pts, S.count,
                        S.pairs, S.segs, d.N, d.ntiles, d.ntap, ds.tap_meta, ds.tap_off, ds.tile_flag,
-                       BWD ? ds.tap_total : nullptr);
+                       BWD ? ds.tap_total : nullptr, BWD ? ds.pop_mask : nullptr);
     hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, S.segs, d.B, d.ntiles, ds.sched_cap, ds.sched);
     if (BWD)
-        hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.tap_off, d.ntap, d.B * d.ntiles, kDwItems,
+        hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.pop_mask, d.ntap, d.B * d.ntiles, kDwItems,
                            ds.items, ds.tap_rng, ds.tap_total + 64);
     return hip_ok();
 }

@@ -68,6 +68,27 @@ constexpr int kDeepBatch = 256;   // records whose metadata is fetched at once
 // population is 0 (.cpp:679) dropped.  Else forward taps, population of the centre's tap; false positives dropped.
 // Tiles whose pair reservation overflowed get an empty order and tile_flag = 1 (the generic kernel takes them).
 // ---------------------------------------------------------------------------------------------
+constexpr int kOrderR = 16;   // records per thread and round of deep_order_kernel (4096 per round)
+
+// Rank of this lane's record among the records of the SAME tap in its wave-chunk (the 64 records the wave holds in
+// one register), the chunk's number of records of that tap, and whether this lane is the first of them.  The lanes
+// with the same key are found bit by bit (ntap <= 64: six ballots) instead of one ballot per tap.
+__device__ __forceinline__ uint32_t chunk_rank(uint32_t key, uint32_t &cnt, bool &leader)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t eq = __ballot(key != 0xFFFFFFFFu);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const bool bit = (key >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        eq &= bit ? m : ~m;
+    }
+    const uint32_t rank = (uint32_t)__popcll(eq & ((1ull << lane) - 1ull));
+    cnt = (uint32_t)__popcll(eq);
+    leader = key != 0xFFFFFFFFu && rank == 0;
+    return rank;
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *__restrict__ pts,
                                                          const int32_t *__restrict__ count,
@@ -76,13 +97,15 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
                                                          uint2 *__restrict__ tap_meta,
                                                          uint32_t *__restrict__ tap_off,
                                                          uint8_t *__restrict__ tile_flag,
-                                                         uint32_t *__restrict__ tap_total)   // [ntap] += (may be null)
+                                                         uint32_t *__restrict__ tap_total,   // [ntap] += (may be null)
+                                                         unsigned long long *__restrict__ pop_mask)   // [tile] (may be null)
 {
+    constexpr int R = kOrderR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *tot = reinterpret_cast<uint32_t *>(smem);            // [ntap]     records per tap (whole tile)
-    uint32_t *base = tot + ntap;                                    // [ntap]     next free slot of each tap
-    uint32_t *wcnt = base + ntap;                                   // [16][ntap] per wave-chunk counts of a super-chunk
-    int32_t *qorig = reinterpret_cast<int32_t *>(wcnt + 16 * ntap); // [64] original indices of the tile's centres
+    uint32_t *tot = reinterpret_cast<uint32_t *>(smem);            // [ntap]        records per tap (whole tile)
+    uint32_t *base = tot + ntap;                                    // [ntap]        next free slot of each tap
+    uint32_t *wcnt = base + ntap;                                   // [ntap][4 * R] per wave-chunk counts of a round
+    int32_t *qorig = reinterpret_cast<int32_t *>(wcnt + 4 * R * ntap);   // [64] original indices of the tile's centres
     const size_t tile = blockIdx.x;
     const int32_t *cnt_cloud = count + (tile / (size_t)ntiles) * (size_t)N * ntap;
     if (threadIdx.x < 64) qorig[threadIdx.x] = pts[tile * kTile + threadIdx.x].idx;
@@ -91,87 +114,116 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tseg.y == kSegOverflow) {
         for (uint32_t f = tid; f <= (uint32_t)ntap; f += 256) toff[f] = 0;
-        if (tid == 0) tile_flag[tile] = 1;
+        if (tid == 0) {
+            tile_flag[tile] = 1;
+            if (pop_mask != nullptr) pop_mask[tile] = 0ull;
+        }
         return;
     }
     if (tid == 0) tile_flag[tile] = 0;
     const PairEntry *seg = pairs + tseg.x;
     const uint32_t n = tseg.y;
-    // tap of a record (0xFFFFFFFF = dropped) and the population its contribution is divided by
-    auto key_of = [&](const PairEntry &en, uint32_t &pop) -> uint32_t {
-        const uint32_t fw = code_fwd(en.code), bw = code_bwd(en.code);
-        pop = 0;
-        if (fw == kNoTap) return 0xFFFFFFFFu;
-        if (BWD) {
-            if (bw == kNoTap) return 0xFFFFFFFFu;
-            pop = (uint32_t)cnt_cloud[(size_t)en.cand * ntap + bw];
-            return pop ? bw : 0xFFFFFFFFu;                          // .cpp:679
-        }
-        pop = (uint32_t)cnt_cloud[(size_t)qorig[code_q(en.code)] * ntap + fw];
-        return fw;
+    auto zero_wcnt = [&]() {
+        for (uint32_t e = tid; e < (uint32_t)(4 * R * ntap); e += 256) wcnt[e] = 0;
     };
     for (uint32_t f = tid; f < (uint32_t)ntap; f += 256) tot[f] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += 256) {                       // totals: order-independent, LDS atomics
-        uint32_t pop;
-        const uint32_t k = key_of(seg[i], pop);
-        if (k != 0xFFFFFFFFu) atomicAdd(&tot[k], 1u);
+    zero_wcnt();
+    __syncthreads();                                                // qorig, tot, wcnt
+    // One round = 256 x R records, R per thread (record s0 + u * 256 + tid: every load of a step is coalesced), all
+    // R record loads issued together, then all R population gathers: two memory latencies per round.  Every load is
+    // unconditional from a clamped index (see deep_gemm_kernel) and nothing is selected on the gathered value itself.
+    //   key[u]  tap of the record (forward / backward), 0xFFFFFFFF = dropped: past the end, false positive, hole,
+    //           or (BWD) empty tap of the neighbour (.cpp:679)
+    //   rec[u]  {neighbour, centre lane | population << 8}
+    auto load_round = [&](uint32_t s0, uint32_t (&key)[R], uint2 (&rec)[R]) {
+        PairEntry en[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const uint32_t i = s0 + (uint32_t)u * 256u + tid;
+            en[u] = seg[i < n ? i : 0u];
+        }
+        uint32_t pop[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const uint32_t fw = code_fwd(en[u].code), bw = code_bwd(en[u].code);
+            const bool ok = s0 + (uint32_t)u * 256u + tid < n && fw != kNoTap && (!BWD || bw != kNoTap);
+            key[u] = ok ? (BWD ? bw : fw) : 0xFFFFFFFFu;
+            const uint32_t row = BWD ? en[u].cand : (uint32_t)qorig[code_q(en[u].code) & 63u];
+            pop[u] = (uint32_t)cnt_cloud[ok ? (size_t)row * ntap + key[u] : (size_t)0];
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (BWD) key[u] = (key[u] != 0xFFFFFFFFu) & (pop[u] != 0u) ? key[u] : 0xFFFFFFFFu;   // .cpp:679
+            rec[u] = make_uint2(en[u].cand, code_q(en[u].code) | (pop[u] << 8));
+        }
+    };
+    // ranks inside the wave-chunks (chunk u * 4 + wave = 64 consecutive records) + the chunks' per-tap counts
+    auto rank_round = [&](const uint32_t (&key)[R], uint32_t (&rank)[R], bool totals) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            uint32_t c;
+            bool leader;
+            rank[u] = chunk_rank(key[u], c, leader);
+            if (leader) {
+                wcnt[key[u] * (4u * R) + (uint32_t)u * 4u + wave] = c;
+                if (totals) atomicAdd(&tot[key[u]], c);             // one add per (chunk, tap): distinct addresses
+            }
+        }
+    };
+    uint32_t key[R], rank[R];
+    uint2 rec[R];
+    const bool single = n <= 256u * R;                              // the whole tile in one round: records stay in registers
+    if (single) {
+        load_round(0, key, rec);
+        rank_round(key, rank, true);
+    } else {
+        for (uint32_t s0 = 0; s0 < n; s0 += 256u * R) {             // totals only (wcnt is rebuilt per round below)
+            load_round(s0, key, rec);
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                uint32_t c;
+                bool leader;
+                chunk_rank(key[u], c, leader);
+                if (leader) atomicAdd(&tot[key[u]], c);
+            }
+        }
     }
     __syncthreads();
     if (tap_total != nullptr && tid < (uint32_t)ntap && tot[tid] != 0) atomicAdd(&tap_total[tid], tot[tid]);
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int f = 0; f < ntap; ++f) {
-            toff[f] = run;
-            base[f] = run;
-            run += tot[f];
+    if (tid < 64) {                                                 // exclusive scan of the totals (ntap <= 64)
+        int total;
+        const int off = wave_excl_scan(tid < (uint32_t)ntap ? (int)tot[tid] : 0, total);
+        if (tid < (uint32_t)ntap) {
+            toff[tid] = (uint32_t)off;
+            base[tid] = (uint32_t)off;
         }
-        toff[ntap] = run;
+        if (tid == 0) toff[ntap] = (uint32_t)total;
+        const uint64_t populated = __ballot(tid < (uint32_t)ntap && tot[tid < (uint32_t)ntap ? tid : 0u] != 0u);
+        if (tid == 0 && pop_mask != nullptr) pop_mask[tile] = populated;
     }
     __syncthreads();
-    // stable ranks, 1024 records (4 per thread, 16 wave-chunks of 64 consecutive records) per round
     uint2 *meta = tap_meta + tseg.x;
-    for (uint32_t s0 = 0; s0 < n; s0 += 1024) {
-        uint32_t key[4], rank[4];
-        uint2 rec[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t i = s0 + (uint32_t)u * 256u + tid;
-            key[u] = 0xFFFFFFFFu;
-            rec[u] = make_uint2(0u, 0u);
-            if (i < n) {
-                const PairEntry en = seg[i];
-                uint32_t pop;
-                key[u] = key_of(en, pop);
-                rec[u] = make_uint2(en.cand, code_q(en.code) | (pop << 8));
-            }
-            rank[u] = 0;
+    for (uint32_t s0 = 0; s0 < n; s0 += 256u * R) {
+        if (!single) {
+            zero_wcnt();
+            __syncthreads();
+            load_round(s0, key, rec);
+            rank_round(key, rank, false);
+            __syncthreads();
         }
-        for (int f = 0; f < ntap; ++f) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint64_t m = __ballot(key[u] == (uint32_t)f);
-                if (key[u] == (uint32_t)f)
-                    rank[u] = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                if (lane == 0) wcnt[((uint32_t)u * 4u + wave) * (uint32_t)ntap + (uint32_t)f] = (uint32_t)__popcll(m);
-            }
-        }
-        __syncthreads();
-        if (tid < (uint32_t)ntap) {                                 // exclusive offsets over the 16 wave-chunks
-            uint32_t run = base[tid];
-            for (int wc = 0; wc < 16; ++wc) {
-                const uint32_t c = wcnt[(uint32_t)wc * (uint32_t)ntap + tid];
-                wcnt[(uint32_t)wc * (uint32_t)ntap + tid] = run;
-                run += c;
-            }
-            base[tid] = run;
+        // exclusive offsets over the 4 * R = 64 wave-chunks of every tap: one wave-wide scan per tap (lane = chunk)
+        for (uint32_t f = wave; f < (uint32_t)ntap; f += 4) {
+            int total;
+            const int c = (int)wcnt[f * (4u * R) + lane];
+            const int off = wave_excl_scan(c, total);
+            const uint32_t b0 = base[f];
+            wcnt[f * (4u * R) + lane] = b0 + (uint32_t)off;
+            if (lane == 0) base[f] = b0 + (uint32_t)total;
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (key[u] != 0xFFFFFFFFu)
-                meta[wcnt[((uint32_t)u * 4u + wave) * (uint32_t)ntap + key[u]] + rank[u]] = rec[u];
+        for (int u = 0; u < R; ++u)
+            if (key[u] != 0xFFFFFFFFu) meta[wcnt[key[u] * (4u * R) + (uint32_t)u * 4u + wave] + rank[u]] = rec[u];
         __syncthreads();
     }
 }
@@ -510,56 +562,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
 constexpr int kPlanMax = 2048;
 constexpr int kPlanTiles = 8192;
 __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restrict__ tap_total,
-                                                         const uint32_t *__restrict__ tap_off, int ntap, int tiles,
+                                                         const unsigned long long *__restrict__ pop_mask, int ntap, int tiles,
                                                          int target, uint4 *__restrict__ items,
                                                          uint2 *__restrict__ tap_rng, uint32_t *__restrict__ nitems)
 {
     __shared__ unsigned long long keys[kPlanMax];
     __shared__ uint32_t t1s[kPlanMax];
-    __shared__ uint32_t prefix[kPlanTiles];
-    __shared__ uint32_t nf[64], ibeg[65], wtot[16];
+    __shared__ uint32_t nf[64], ibeg[65], wtot[2][16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) {
+    if (tid < 64) {
         // n_f = floor share, at least 1, at most one item per tile; the items left over go to the taps with the
-        // largest remainders, so that the total is EXACTLY `target` whenever that is possible
-        unsigned long long sum = 0;
-        for (int f = 0; f < ntap; ++f) sum += tap_total[f];
-        uint32_t rem[64];
-        uint32_t used = 0;
-        for (int f = 0; f < ntap; ++f) {
-            const unsigned long long share = sum ? (unsigned long long)tap_total[f] * (unsigned)target : 0ull;
-            uint32_t n = sum ? (uint32_t)(share / sum) : 1u;
-            rem[f] = sum ? (uint32_t)(share % sum * 1024ull / sum) : 0u;
-            if (n < 1u) { n = 1u; rem[f] = 0; }
-            if (n > (uint32_t)tiles) { n = (uint32_t)tiles; rem[f] = 0; }
-            if (n < 1u) n = 1u;
-            nf[f] = n;
-            used += n;
+        // largest remainders (ties: lower tap), so that the total is EXACTLY `target` whenever that is possible.
+        // lane = tap (ntap <= 64).
+        const bool on = tid < (uint32_t)ntap;
+        const uint32_t mytot = on ? tap_total[tid] : 0u;
+        unsigned long long sum = mytot;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const unsigned long long share = sum ? (unsigned long long)mytot * (unsigned)target : 0ull;
+        uint32_t n = sum ? (uint32_t)(share / sum) : 1u;
+        uint32_t rem = sum ? (uint32_t)(share % sum * 1024ull / sum) : 0u;
+        if (n < 1u) { n = 1u; rem = 0; }
+        if (n > (uint32_t)tiles) { n = (uint32_t)tiles; rem = 0; }
+        if (n < 1u) n = 1u;
+        if (!on) { n = 0; rem = 0; }
+        int used_i;
+        (void)wave_excl_scan((int)n, used_i);
+        const uint32_t left = (uint32_t)used_i < (uint32_t)target ? (uint32_t)target - (uint32_t)used_i : 0u;
+        const bool elig = on && n < (uint32_t)tiles && rem > 0;
+        uint32_t ahead = 0;                                   // eligible taps that are served before this one
+        for (int g = 0; g < ntap; ++g) {
+            const uint32_t rg = __shfl(rem, g);
+            const bool eg = __shfl((int)elig, g) != 0;
+            ahead += (eg && (rg > rem || (rg == rem && (uint32_t)g < tid))) ? 1u : 0u;
         }
-        while (used < (uint32_t)target) {
-            int best = -1;
-            for (int f = 0; f < ntap; ++f)
-                if (nf[f] < (uint32_t)tiles && rem[f] > 0 && (best < 0 || rem[f] > rem[best])) best = f;
-            if (best < 0) break;
-            nf[best] += 1;
-            rem[best] = 0;
-            used += 1;
+        if (elig && ahead < left) n += 1;
+        int run_total;
+        const uint32_t run = (uint32_t)wave_excl_scan((int)n, run_total);
+        if (on) {
+            nf[tid] = n;
+            ibeg[tid] = run;
+            tap_rng[tid] = make_uint2(run, n);
         }
-        uint32_t run = 0;
-        for (int f = 0; f < ntap; ++f) {
-            ibeg[f] = run;
-            tap_rng[f] = make_uint2(run, nf[f]);
-            run += nf[f];
+        if (tid == 0) {
+            ibeg[ntap] = (uint32_t)run_total;
+            *nitems = (uint32_t)run_total;
         }
-        ibeg[ntap] = run;
-        *nitems = run;
     }
     __syncthreads();
     const uint32_t total = ibeg[ntap];                       // <= target + ntap <= kPlanMax (host checks)
     const uint32_t T = (uint32_t)tiles;
+    // populated-tap masks of this thread's contiguous run of `per` tiles: ONE global read for all taps
+    const uint32_t per = (T + 1023u) / 1024u;
+    unsigned long long mask[kPlanTiles / 1024];
+#pragma unroll
+    for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) {
+        const uint32_t t = tid * per + u;
+        const unsigned long long m = pop_mask[T <= (uint32_t)kPlanTiles && u < per && t < T ? t : 0u];
+        mask[u] = T <= (uint32_t)kPlanTiles && u < per && t < T ? m : 0ull;
+    }
     for (int f = 0; f < ntap; ++f) {
         const uint32_t n = nf[f], i0 = ibeg[f];
-        if (T > (uint32_t)kPlanTiles) {                      // too many tiles for the LDS prefix: equal tile ranges
+        if (T > (uint32_t)kPlanTiles) {                      // too many tiles for one run per thread: equal tile ranges
             for (uint32_t j = tid; j < n; j += 1024) {
                 const uint32_t t0 = (uint32_t)((unsigned long long)j * T / n);
                 keys[i0 + j] = ((unsigned long long)t0 << 32) | ((unsigned long long)f << 16) | j;
@@ -567,76 +631,51 @@ __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restr
             }
             continue;
         }
-        // work of every tile for this tap -> inclusive prefix (thread = contiguous run of `per` tiles)
-        const uint32_t per = (T + 1023u) / 1024u;
-        uint32_t w[kPlanTiles / 1024], mine = 0;
+        // work of a tile for this tap = 1 if it is populated (one [Cin x 64].[64 x Cout] product).  Item j of the
+        // tap starts at b_j = the first tile whose inclusive work prefix exceeds floor(wall * j / n) (b_0 = 0), i.e.
+        // the populated tile with exclusive prefix e starts exactly the items j in
+        // [ceil(e * n / wall), ceil((e + 1) * n / wall)): every thread walks its own tiles with a running prefix and
+        // writes those items -- no prefix array, no search, one barrier per tap.
+        uint32_t mine = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) {
-            const uint32_t t = tid * per + u;
-            w[u] = 0;
-            if (u < per && t < T) {
-                const uint32_t c = tap_off[(size_t)t * (ntap + 1) + f + 1] - tap_off[(size_t)t * (ntap + 1) + f];
-                w[u] = c ? 1u : 0u;                           // one [Cin x 64].[64 x Cout] product per populated tile
-            }
-            mine += w[u];
-        }
+        for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) mine += (uint32_t)((mask[u] >> f) & 1ull);
         int wsum;
         uint32_t excl = (uint32_t)wave_excl_scan((int)mine, wsum);
-        if (lane == 0) wtot[wave] = (uint32_t)wsum;
-        __syncthreads();
-        uint32_t base = 0;
-        for (uint32_t k = 0; k < wave; ++k) base += wtot[k];
-        excl += base;
+        if (lane == 0) wtot[f & 1][wave] = (uint32_t)wsum;
+        __syncthreads();                                     // (wtot is double-buffered: one barrier per tap)
+        uint32_t wall = 0;
+        for (uint32_t k = 0; k < 16; ++k) {
+            if (k == wave) excl += wall;
+            wall += wtot[f & 1][k];
+        }
+        if (tid == 0) {
+            keys[i0] = ((unsigned long long)f << 16);        // item 0 starts at the first tile
+            t1s[i0 + n - 1] = T;                              // the last item ends at the last tile
+        }
 #pragma unroll
         for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) {
+            if (((mask[u] >> f) & 1ull) == 0) continue;
             const uint32_t t = tid * per + u;
-            excl += w[u];
-            if (u < per && t < T) prefix[t] = excl;
+            const unsigned long long e = excl;
+            excl += 1;
+            uint32_t ja = (uint32_t)((e * n + wall - 1) / wall), jb = (uint32_t)(((e + 1) * n + wall - 1) / wall);
+            if (jb > n) jb = n;
+            for (uint32_t j = ja > 0 ? ja : 1u; j < jb; ++j) {
+                keys[i0 + j] = ((unsigned long long)t << 32) | ((unsigned long long)f << 16) | j;
+                t1s[i0 + j - 1] = t;
+            }
         }
-        __syncthreads();
-        const unsigned long long wall = prefix[T - 1];
-        // boundary b_j = first tile whose inclusive prefix exceeds j * wall / n  (b_0 = 0 by construction: item 0
-        // starts at the first tile; empty leading tiles cost nothing)
-        for (uint32_t j = tid; j < n; j += 1024) {
-            auto bound = [&](uint32_t jj) -> uint32_t {
-                if (jj == 0) return 0u;
-                if (jj >= n) return T;
-                const uint32_t goal = (uint32_t)(wall * jj / n);
-                uint32_t lo = 0, hi = T;                      // first t with prefix[t] > goal
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (prefix[mid] > goal) hi = mid; else lo = mid + 1;
-                }
-                return lo;
-            };
-            const uint32_t t0 = bound(j);
-            keys[i0 + j] = ((unsigned long long)t0 << 32) | ((unsigned long long)f << 16) | j;
-            t1s[i0 + j] = bound(j + 1);
-        }
-        __syncthreads();
     }
     __syncthreads();
-    // issue order: by first tile (then tap); t1 travels in a second array addressed by slot
-    uint32_t npad = 1;
-    while (npad < total) npad <<= 1;
-    for (uint32_t i = total + tid; i < npad; i += 1024) keys[i] = ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= npad; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < npad; t += 1024) {
-                const uint32_t p = t ^ j;
-                if (p > t) {
-                    const unsigned long long a = keys[t], b = keys[p];
-                    const bool up = (t & k) == 0;
-                    if ((a > b) == up) { keys[t] = b; keys[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    // issue order: by first tile (then tap, then j); keys are distinct, so an item's position is the number of smaller
+    // keys (every thread reads the same LDS words: broadcasts) -- a bitonic sort spent ~70 barriers here
     for (uint32_t i = tid; i < total; i += 1024) {
-        const uint32_t f = (uint32_t)(keys[i] >> 16) & 0xFFFFu, j = (uint32_t)keys[i] & 0xFFFFu;
+        const unsigned long long k = keys[i];
+        uint32_t pos = 0;
+        for (uint32_t m = 0; m < total; ++m) pos += keys[m] < k ? 1u : 0u;
+        const uint32_t f = (uint32_t)(k >> 16) & 0xFFFFu, j = (uint32_t)k & 0xFFFFu;
         const uint32_t slot = ibeg[f] + j;
-        items[i] = make_uint4(f, (uint32_t)(keys[i] >> 32), t1s[slot], slot);
+        items[pos] = make_uint4(f, (uint32_t)(k >> 32), t1s[slot], slot);
     }
 }
 

@@ -811,7 +811,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 // unconditional from clamped addresses, so hipcc can count the ones in flight.
                 // (NS = 2 for the widest rows, whose three copies would not fit the register file: the row is then
                 // loaded in the step that uses it, as before)
-                constexpr int NS = sizeof(T) * CIN <= 144 ? 3 : 2;
+#ifndef CONV3P_FWD_SLOTS
+#define CONV3P_FWD_SLOTS 3
+#endif
+                constexpr int NS = sizeof(T) * CIN <= 48 ? CONV3P_FWD_SLOTS : sizeof(T) * CIN <= 144 ? 3 : 2;
                 PairEntry rec[NS];
                 T xs[NS][CIN];
                 auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
@@ -955,6 +958,14 @@ __global__ __launch_bounds__(256) void backward_kernel(
     off += align16((size_t)kWavesPerBlock * 192 * 4);
     const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense phase A: centre and sub-lane
 
+#if CONV3P_ABLATE & 33554432
+    long long bt[8];
+    int bti = 0;
+#define BDBG() { __builtin_amdgcn_s_waitcnt(0); bt[bti++] = wall_clock64(); }
+#else
+#define BDBG()
+#endif
+    BDBG()
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     if constexpr (kSmall) {
         // filter -> LDS transposed to [row = (f,c)][k]: coalesced global reads, 8 per thread in flight
@@ -998,6 +1009,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
         }
     }
     __syncthreads();
+    BDBG()
 
     if (live) {
         const int32_t *cnt_cloud = count + (size_t)b * N * st.ntap;
@@ -1066,38 +1078,38 @@ __global__ __launch_bounds__(256) void backward_kernel(
                         return cnt_cloud[live ? (size_t)r.cand * st.ntap + code_bwd(r.code) : (size_t)0];
                     };
                     // With 78 KB of LDS only two workgroups fit a CU, so the latency of the gathers is hidden by depth,
-                    // not by occupancy: the record of step k+3 and the dY row + population of step k+2 are in flight
-                    // while step k runs.  Four NAMED slots, the loop unrolled by four: a slot is a fixed set of
-                    // registers.  (Rotating slots by register copies made every step wait for the newest load -- a
-                    // copy reads its destination -- so the "pipeline" drained the queue every step.)
-                    PairEntry rec[4];
-                    bool lv[4];
-                    int cn[4];
-                    T val[4][COUT];
+                    // not by occupancy: kDepth NAMED slots, the loop unrolled by kDepth so that a slot is a fixed set of
+                    // registers; the record of step k+kDepth-1 and the dY row + population of step k+kDepth-2 are in
+                    // flight while step k runs.  (Rotating slots by register copies made every step wait for the
+                    // newest load -- a copy reads its destination -- so that "pipeline" drained the queue every step.)
+                    constexpr int kDepth = 4;   // measured: 8 slots (whole lists requested up front) is 3 % slower on cfg2
+                    PairEntry rec[kDepth];
+                    bool lv[kDepth];
+                    int cn[kDepth];
+                    T val[kDepth][COUT];
                     auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
                     auto gather = [&](int sl, uint32_t i) {
                         lv[sl] = live_rec(rec[sl], i);
                         cn[sl] = cnt_of(rec[sl], lv[sl]);
                         RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy, val[sl]);
                     };
-                    rec[0] = ld_rec(sub);
-                    rec[1] = ld_rec(sub + 4);
-                    rec[2] = ld_rec(sub + 8);
-                    __builtin_amdgcn_sched_barrier(0);   // the three records are the oldest loads in flight on entry
-                    gather(0, sub);
-                    gather(1, sub + 4);
+#pragma unroll
+                    for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = ld_rec(sub + 4 * sl);
+                    __builtin_amdgcn_sched_barrier(0);   // the records are the oldest loads in flight on entry
+#pragma unroll
+                    for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, sub + 4 * sl);
                     T ablate_sink = (T)0;
                     uint32_t i = sub;
                     bool more = true;
                     while (more) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < kDepth; ++j) {
                             if (!__any(i < sg.y)) {
                                 more = false;
                                 break;
                             }
-                            rec[(j + 3) & 3] = ld_rec(i + 12);
-                            gather((j + 2) & 3, i + 8);
+                            rec[(j + kDepth - 1) % kDepth] = ld_rec(i + 4 * (kDepth - 1));
+                            gather((j + kDepth - 2) % kDepth, i + 4 * (kDepth - 2));
                             __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of this step's arithmetic
                             // false positive, hole, or empty tap (.cpp:679) -> contributes nothing
                             bool pending = lv[j] & (cn[j] != 0);
@@ -1186,7 +1198,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
     }
 
     if constexpr (kSmall) {
+        BDBG()
         __syncthreads();
+        BDBG()
         // ---- phase B: dW rows.  thread = row (f,c); X tile read with wave-uniform addresses.
         T *slot = partials + (size_t)blockIdx.x * nw;
         for (int row = threadIdx.x; row < ((CONV3P_ABLATE & 2) ? 0 : nrows); row += blockDim.x) {
@@ -1208,6 +1222,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
 #pragma unroll
             for (int k = 0; k < CIN; ++k) slot[((size_t)f * CIN + k) * COUT + c] = acc[k];
         }
+        BDBG()
         // ---- phase C: dX rows.  lane = centre j, waves split the rows.
         T dx[CIN];
 #pragma unroll
@@ -1236,6 +1251,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
             }
         }
+        BDBG()
         __syncthreads();   // red aliases wt / xt: every wave is done reading them
 #pragma unroll
         for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
@@ -1252,6 +1268,12 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     grad_input[r * ld.dx + k] = sum;
                 }
             }
+#if CONV3P_ABLATE & 33554432
+        BDBG()
+        if (lane == 0 && (blockIdx.x % 211) == 7)   // developer instrumentation build only (10 ns ticks)
+            printf("bwd<%d,%d> wg %d wave %d: prologue %lld  phaseA %lld  sync %lld  B %lld  C %lld  reduce+store %lld\n", CIN, COUT,
+                   (int)blockIdx.x, wave, bt[1] - bt[0], bt[2] - bt[1], bt[3] - bt[2], bt[4] - bt[3], bt[5] - bt[4], bt[6] - bt[5]);
+#endif
     }
 }
 
