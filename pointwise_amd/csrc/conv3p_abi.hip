@@ -503,6 +503,7 @@ struct DeepScratch {   // carved from the per-call scratch region
     uint32_t *tap_off;     // [tiles][F+1]
     uint8_t *tile_flag;    // [tiles]
     unsigned long long *pop_mask;   // [tiles] bit f: the tile has records of backward tap f (deep_order -> deep_plan)
+    uint4 *tap_split;      // [tiles][F] quarter points of every (tile, tap) run (deep_order -> deep_gemm stage 1)
     uint32_t *sched;       // [8][sched_cap] launch order of the tiles per XCD (deep_sched_kernel)
     int sched_cap;
     uint32_t *tap_total;   // [64] pairs per backward tap, then [1] number of work items  (deep_plan_kernel)
@@ -526,6 +527,7 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
     s.pop_mask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * 8));
+    s.tap_split = reinterpret_cast<uint4 *>(take((size_t)d.B * d.ntiles * d.ntap * 16));
     s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
     s.sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
     s.tap_total = reinterpret_cast<uint32_t *>(take(65 * 4));
@@ -544,12 +546,12 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     const Dims &d = c.d;
     if (d.ntap > 64) return CONV3P_ERR_UNSUPPORTED;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = (size_t)(2 + 4 * kOrderR) * d.ntap * 4 + 256;
+    const size_t lds = (size_t)(2 + 4 * kOrderR + 64) * d.ntap * 4 + 256;
     Scope sc(K_DEEP_ORDER, c.s);
     if (BWD) TRY(zero_async(ds.tap_total, 65 * 4, c.s));
     hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, c.L.pts, S.count,
                        S.pairs, S.segs, d.N, d.ntiles, d.ntap, ds.tap_meta, ds.tap_off, ds.tile_flag,
-                       BWD ? ds.tap_total : nullptr, BWD ? ds.pop_mask : nullptr);
+                       BWD ? ds.tap_total : nullptr, BWD ? ds.pop_mask : nullptr, ds.tap_split);
     hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, S.segs, d.B, d.ntiles, ds.sched_cap, ds.sched);
     if (BWD)
         hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.pop_mask, d.ntap, d.B * d.ntiles, kDwItems,
@@ -563,15 +565,24 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
 {
     const Dims &d = c.d;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = a16((size_t)(KD < 256 ? 256 / KD : 1) * 64 * (KD + 1) * 4) + 4 * (size_t)kDeepBatch * 4 + 256 + 1024;
+    const size_t lds = a16((size_t)(KD < 256 ? 256 / KD : 1) * 64 * (KD + 4) * 4) + 68 * 4 + 256 + 4096;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
     Scope sc(K_DEEP_GEMM, c.s);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_gemm_kernel<KD, ND, BWD>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((deep_gemm_kernel<KD, ND, BWD>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs,
-                       S.segs, src, Bm, d.N, d.ntiles, d.ntap, ds.sched, ds.sched_cap, out, ds.tap_meta, ds.tap_off,
-                       ds.tile_flag, kreal, nreal, gbuf, xin);
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs, S.segs, src, Bm, d.N, d.ntiles,
+                           d.ntap, ds.sched, ds.sched_cap, out, ds.tap_meta, ds.tap_off, ds.tile_flag, kreal, nreal, gbuf, xin,
+                           ds.tap_split);
+    };
+    // rows shorter than 4 floats (only possible in the 32-column class) take the variant with scalar row loads
+    if constexpr (KD == 32) {
+        if (kreal < 4) {
+            go(deep_gemm_kernel<KD, ND, BWD, false>);
+            return hip_ok();
+        }
+    }
+    go(deep_gemm_kernel<KD, ND, BWD, true>);
     return hip_ok();
 }
 
@@ -606,7 +617,6 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
                   float *grad_input, float *grad_filter)
 {
     const Dims &d = c.d;
-    const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
     const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials);
     TRY(launch_deep_order<true>(c, ds));

@@ -55,13 +55,12 @@ __device__ __forceinline__ float4 load_row4(const float *__restrict__ row, int c
 }
 
 constexpr int kDeepBlk = 32;      // records per staged block (= 16 MFMA k-steps)
-constexpr int kDeepBatch = 256;   // records whose metadata is fetched at once
 
 // ---------------------------------------------------------------------------------------------
 // deep_order_kernel: tap-major order of every query tile's records (stable counting sort by tap: taps ascending,
 // inside a tap the search's record order -> deterministic).  One workgroup per tile.
 //   tap_off[tile][f] .. tap_off[tile][f+1] : slots of tap f (relative to the tile's segment)
-//   tap_meta[segment start + slot]         : {neighbour's original index, centre lane | population << 8} of the
+//   tap_meta[segment start + slot]         : {neighbour's original index | centre lane << 24, 1 / population} of the
 //                                            record in that slot -- everything the GEMM kernels need of a record, so
 //                                            they fetch it with ONE load (no order -> record -> population chain)
 // BWD: taps = backward taps, population = that of the neighbour's tap (one 4-byte gather); holes and records whose
@@ -98,7 +97,8 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
                                                          uint32_t *__restrict__ tap_off,
                                                          uint8_t *__restrict__ tile_flag,
                                                          uint32_t *__restrict__ tap_total,   // [ntap] += (may be null)
-                                                         unsigned long long *__restrict__ pop_mask)   // [tile] (may be null)
+                                                         unsigned long long *__restrict__ pop_mask,   // [tile] (may be null)
+                                                         uint4 *__restrict__ tap_split)   // [tile][ntap] quarter points of every run
 {
     constexpr int R = kOrderR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
     uint32_t *base = tot + ntap;                                    // [ntap]        next free slot of each tap
     uint32_t *wcnt = base + ntap;                                   // [ntap][4 * R] per wave-chunk counts of a round
     int32_t *qorig = reinterpret_cast<int32_t *>(wcnt + 4 * R * ntap);   // [64] original indices of the tile's centres
+    uint32_t *hist = reinterpret_cast<uint32_t *>(qorig + 64);     // [ntap][64] records per (tap, centre)
     const size_t tile = blockIdx.x;
     const int32_t *cnt_cloud = count + (tile / (size_t)ntiles) * (size_t)N * ntap;
     if (threadIdx.x < 64) qorig[threadIdx.x] = pts[tile * kTile + threadIdx.x].idx;
@@ -127,14 +128,15 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
         for (uint32_t e = tid; e < (uint32_t)(4 * R * ntap); e += 256) wcnt[e] = 0;
     };
     for (uint32_t f = tid; f < (uint32_t)ntap; f += 256) tot[f] = 0;
+    for (uint32_t e = tid; e < (uint32_t)ntap * 64u; e += 256) hist[e] = 0;
     zero_wcnt();
-    __syncthreads();                                                // qorig, tot, wcnt
+    __syncthreads();                                                // qorig, tot, wcnt, hist
     // One round = 256 x R records, R per thread (record s0 + u * 256 + tid: every load of a step is coalesced), all
     // R record loads issued together, then all R population gathers: two memory latencies per round.  Every load is
     // unconditional from a clamped index (see deep_gemm_kernel) and nothing is selected on the gathered value itself.
     //   key[u]  tap of the record (forward / backward), 0xFFFFFFFF = dropped: past the end, false positive, hole,
     //           or (BWD) empty tap of the neighbour (.cpp:679)
-    //   rec[u]  {neighbour, centre lane | population << 8}
+    //   rec[u]  {neighbour | centre lane << 24, 1 / population}
     auto load_round = [&](uint32_t s0, uint32_t (&key)[R], uint2 (&rec)[R]) {
         PairEntry en[R];
 #pragma unroll
@@ -153,8 +155,10 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            if (BWD) key[u] = (key[u] != 0xFFFFFFFFu) & (pop[u] != 0u) ? key[u] : 0xFFFFFFFFu;   // .cpp:679
-            rec[u] = make_uint2(en[u].cand, code_q(en[u].code) | (pop[u] << 8));
+            if (BWD) key[u] = ((key[u] != 0xFFFFFFFFu) & (pop[u] != 0u)) ? key[u] : 0xFFFFFFFFu;   // .cpp:679
+            // {neighbour | centre lane << 24, bits of 1 / population}: the IEEE quotient, as the register path
+            // computes it (a dropped record's population may be 0: its reciprocal is never used)
+            rec[u] = make_uint2(en[u].cand | (code_q(en[u].code) << 24), __builtin_bit_cast(uint32_t, 1.0f / (float)pop[u]));
         }
     };
     // ranks inside the wave-chunks (chunk u * 4 + wave = 64 consecutive records) + the chunks' per-tap counts
@@ -170,12 +174,18 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
             }
         }
     };
+    auto hist_round = [&](const uint32_t (&key)[R], const uint2 (&rec)[R]) {
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+            if (key[u] != 0xFFFFFFFFu) atomicAdd(&hist[key[u] * 64u + (rec[u].x >> 24)], 1u);
+    };
     uint32_t key[R], rank[R];
     uint2 rec[R];
     const bool single = n <= 256u * R;                              // the whole tile in one round: records stay in registers
     if (single) {
         load_round(0, key, rec);
         rank_round(key, rank, true);
+        hist_round(key, rec);
     } else {
         for (uint32_t s0 = 0; s0 < n; s0 += 256u * R) {             // totals only (wcnt is rebuilt per round below)
             load_round(s0, key, rec);
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
                 chunk_rank(key[u], c, leader);
                 if (leader) atomicAdd(&tot[key[u]], c);
             }
+            hist_round(key, rec);
         }
     }
     __syncthreads();
@@ -202,6 +213,27 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
         if (tid == 0 && pop_mask != nullptr) pop_mask[tile] = populated;
     }
     __syncthreads();
+    // Quarter points of every tap's run, moved forward to the next change of centre (a run is centre-major, centres in
+    // lane order): deep_gemm_kernel's stage 1 walks the four parts of a run with four thread groups, and a centre
+    // must belong to exactly one of them.  split[f] = {a1, a2, a3, length}, positions relative to the run's start.
+    if (tap_split != nullptr)
+        for (uint32_t f = wave; f < (uint32_t)ntap; f += 4) {
+            int len;
+            const int excl = wave_excl_scan((int)hist[f * 64u + lane], len);   // records of the centres before `lane`
+            uint32_t a[3];
+#pragma unroll
+            for (int r = 1; r <= 3; ++r) {
+                const uint32_t goal = (uint32_t)len * (uint32_t)r / 4u;
+                uint32_t best = (uint32_t)excl >= goal ? (uint32_t)excl : (uint32_t)len;   // boundaries at or after the goal
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t other = __shfl_xor(best, o);
+                    best = other < best ? other : best;
+                }
+                a[r - 1] = best;
+            }
+            if (lane == 0) tap_split[tile * (size_t)ntap + f] = make_uint4(a[0], a[1], a[2], (uint32_t)len);
+        }
     uint2 *meta = tap_meta + tseg.x;
     for (uint32_t s0 = 0; s0 < n; s0 += 256u * R) {
         if (!single) {
@@ -282,38 +314,22 @@ __device__ __forceinline__ int qorig_early(const PointRec<float> *__restrict__ p
     return pts[tile_id * kTile + q].idx;
 }
 
-// metadata of up to kDeepBatch records of one (tile, tap) run -> LDS (thread = record: one coalesced load).
-// mrec[t] = {first element of the neighbour's row (index * row length), centre lane, bits of 1/count, -}: one
-// 16-byte LDS read per record in stage 1.  Entries past the run: row 0, centre 64 (matches no lane), weight 0.
-__device__ __forceinline__ void deep_fetch_meta(const uint2 *__restrict__ meta, uint32_t e0, uint32_t e1, uint32_t kreal,
-                                                uint4 *mrec)
-{
-    const uint32_t t = threadIdx.x;
-    uint32_t cand = 0, q = 64;
-    float rcp = 0.0f;
-    if (e0 + t < e1) {
-        uint2 m;
-        if (CONV3P_ABLATE & 4194304) m = make_uint2((e0 + t) & 1023u, (t & 63u) | (1u << 8));
-        else m = meta[e0 + t];
-        cand = m.x;
-        q = m.y & 0xFFu;
-        rcp = 1.0f / (float)(m.y >> 8);       // the IEEE quotient, as the register path computes it
-    }
-    mrec[t] = make_uint4(cand * kreal, q, __builtin_bit_cast(uint32_t, rcp), 0u);   // < 2^31: N * kreal floats per cloud
-}
-
 // ---------------------------------------------------------------------------------------------
 // deep_gemm_kernel: out[centre, 0..NDIM) = sum_f M_f[centre, 0..KDIM) . Bm[f][KDIM][NDIM]
 //   BWD = false : forward.    src = input    (rows of KDIM = Cin),  order/weights of the forward taps, Bm = filter
 //   BWD = true  : grad_input. src = grad_out (rows of KDIM = Cout), backward taps, Bm = filter^T ([F][Cout][Cin])
 // One workgroup (4 waves) per query tile; per tap:
-//   stage 1  M_f[centre] = segmented sum of the tap's neighbour rows / count on the vector ALUs (thread = column,
-//            rows straight from global memory, 2 x 16 loads in flight per thread) -> LDS [kGroups][64][KDIM+1]
-//   stage 2  out += M_f . Bm[f]          the 2 x NDIM/32 output blocks dealt to the waves, accumulators in registers
-//                                        across all taps, B operand streamed from L2
-// LDS: M_f [kGroups][64][KDIM+1] | meta {row start, centre, 1/count, -} [256] | qorig [64] | scrap [256]
+//   stage 1  M_f[centre] = segmented sum of the tap's neighbour rows / count on the vector ALUs.  The 256 threads
+//            form TG = 256 / KDIM groups of KDIM threads (thread = column); every group takes ONE tap of the current
+//            super-step and walks that tap's run on its own (rows and record metadata straight from global memory,
+//            software-pipelined), so the super-step's TG taps proceed concurrently without any barrier or shared
+//            staging between them -> LDS M [TG][64][KDIM+1]
+//   stage 2  out += M_f . Bm[f] for the super-step's taps: the 2 x NDIM/32 output blocks dealt to the waves,
+//            accumulators in registers across all taps, B operand streamed from L2
+// The populated taps are taken longest run first (taps running together have similar lengths).
+// LDS: M [TG][64][KDIM+4] | taps [64] | qorig [64] | scrap [256][4]
 // ---------------------------------------------------------------------------------------------
-template <int KDIM, int NDIM, bool BWD>
+template <int KDIM, int NDIM, bool BWD, bool WIDE>   // WIDE: source rows have at least 4 floats (one 16-byte load per lane)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_WAVES))) void deep_gemm_kernel(const PointRec<float> *__restrict__ pts,
                                                         const PairEntry *__restrict__ pairs,
                                                         const uint2 *__restrict__ segs,
@@ -326,27 +342,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                                                         uint8_t *__restrict__ tile_flag,
                                                         int kreal, int nreal,   // real row lengths of src / out
                                                         float *__restrict__ gbuf,   // BWD: [tile][tap][64][KDIM] <- M_f
-                                                        const float *__restrict__ xin)   // BWD: the layer's input
+                                                        const float *__restrict__ xin,   // BWD: the layer's input
+                                                        const uint4 *__restrict__ tap_split)   // [tile][tap] quarter points
 {
-    constexpr int LDA = KDIM + 1;
-    constexpr int kGroups = KDIM < 256 ? 256 / KDIM : 1;   // copies of M_f (stage 1's thread groups, one per 256 / KDIM)
+    constexpr int LDA = KDIM + 4;                         // rows 16-byte aligned (stage 1 stores 4 columns at once)
+    constexpr int TG = KDIM < 256 ? 256 / KDIM : 1;        // taps per super-step = thread groups of stage 1
     // 32x32 blocks of M_f (2 x KDIM/32) and of the output (2 x NDIM/32) are dealt to the 4 waves so that every
     // index below is a compile-time constant (accumulators stay in AGPRs, no predicated MFMAs): wave w owns the
     // row block w & 1 and the column blocks (w >> 1) + 2j.  With a single column block (32 channels) only
     // waves 0 and 1 take part.
     constexpr int CBK = KDIM / 32;                        // column blocks of M_f
-    constexpr int SPW = CBK >= 2 ? CBK / 2 : 1;           // ... per wave
     constexpr int CBN = NDIM / 32;                        // column blocks of the output
     constexpr int OPW = CBN >= 2 ? CBN / 2 : 1;
     constexpr int KG = 8;                                 // MFMA k-steps per B-operand prefetch group
     static_assert(KDIM % 32 == 0 && NDIM % 32 == 0 && KDIM <= 256 && (CBK == 1 || CBK % 2 == 0) && (CBN == 1 || CBN % 2 == 0),
                   "deep path: channel counts are 32 or multiples of 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *A = reinterpret_cast<float *>(smem);           // M_f [kGroups][64][LDA] (partial sums, added on read)
-    size_t off = align16((size_t)kGroups * 64 * LDA * 4);
-    uint4 *mrec = reinterpret_cast<uint4 *>(smem + off);
-    int32_t *qorig = reinterpret_cast<int32_t *>(mrec + kDeepBatch);
-    float *scrap = reinterpret_cast<float *>(qorig + 64);   // [256] write-only (stage 1's predicated-off stores)
+    float *A = reinterpret_cast<float *>(smem);           // M_f of the super-step's taps [TG][64][LDA]
+    size_t off = align16((size_t)TG * 64 * LDA * 4);
+    uint32_t *taps = reinterpret_cast<uint32_t *>(smem + off);   // [64] populated taps, longest run first; [64] = how many
+    int32_t *qorig = reinterpret_cast<int32_t *>(taps + 68);
+    float *scrap = reinterpret_cast<float *>(qorig + 64);   // [256][4] write-only (stage 1's predicated-off stores)
 
     // workgroup -> tile: XCD (blockIdx.x & 7, as in BlockMap) and position in that XCD's longest-first order
     const uint32_t tile_sched = sched[(size_t)(blockIdx.x & 7) * sched_cap + (blockIdx.x >> 3)];
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     const int b = (int)(tile_sched / (uint32_t)ntiles), qt = (int)(tile_sched % (uint32_t)ntiles);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rb = wave & 1, cb0 = wave >> 1;             // this wave's row block and first column block
-    const bool s_on = CBK >= 2 || wave < 2, o_on = CBN >= 2 || wave < 2;
+    const bool o_on = CBN >= 2 || wave < 2;
     const uint32_t myrow = (uint32_t)(rb * 32 + (lane & 31));
     const size_t tile_id = (size_t)b * ntiles + qt;
     const uint2 tseg = segs[tile_id];
@@ -398,139 +414,210 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     }
 #if CONV3P_ABLATE & 16777216
     long long gk[6] = {0, 0, 0, 0, 0, 0};
-    long long gblk = 0, gtap = 0;
+    long long gstart = wall_clock64();
 #define GDBG(i) { const long long t_ = wall_clock64(); gk[i] += t_ - glast; glast = t_; }
     long long glast = wall_clock64();
 #else
 #define GDBG(i)
 #endif
-    for (int f = 0; f < ntap; ++f) {
-        const uint32_t e0 = toff[f], e1 = toff[f + 1];
-        if (e0 == e1) continue;                              // block-uniform
-        // ---- stage 1: M_f[centre] = sum over the centre's records of this tap of row[neighbour] / count.
+    // populated taps, longest run first (ties: lower tap): position = number of taps ahead (wave 0, lane = tap)
+    if (wave == 0) {
+        const uint32_t len = lane < ntap ? toff[lane + 1] - toff[lane] : 0u;
+        uint32_t pos = 0;
+        for (int g = 0; g < ntap; ++g) {
+            const uint32_t lg = __shfl(len, g);
+            pos += (lg > len || (lg == len && g < lane)) ? 1u : 0u;
+        }
+        if (len != 0) taps[pos] = (uint32_t)lane;
+        const uint64_t ne = __ballot(len != 0);
+        if (lane == 0) taps[64] = (uint32_t)__popcll(ne);
+    }
+    __syncthreads();
+    const int nne = (int)taps[64];
+    // stage 1 thread layout: LPR = KDIM / 4 lanes per record (thread = 4 consecutive columns, ONE 16-byte load per
+    // record and lane), 256 / LPR = 4 * TG groups: the four groups 4g .. 4g+3 walk the four parts of tap slot g's run
+    constexpr int LPR = KDIM / 4;
+    const int tl = (int)threadIdx.x % LPR, grp = (int)threadIdx.x / LPR;
+    const int gslot = grp >> 2, part = grp & 3;
+    const int col0 = 4 * tl;
+    // columns [col0, col0 + 4) of a row of kreal floats with one unconditional 16-byte load: the load starts at
+    // min(col0, kreal - 4) and the values are shifted into place (`shl` = 0 for full chunks; >= 4: all padding)
+    constexpr bool wide = WIDE;
+    const int lstart = wide ? (col0 < kreal - 4 ? col0 : kreal - 4) : 0;
+    const int shl = col0 - lstart;
+    float *Ag = A + gslot * 64 * LDA + col0;
+    float *dummy = scrap + 4 * threadIdx.x;                  // where the stores of steps past the run's end go
+    for (int t0 = 0; t0 < nne; t0 += TG) {
+        // ---- stage 1: M_f[centre] = sum over the centre's records of tap f of row[neighbour] / count.
         // A tap's records are centre-major (the search's order, kept by the stable sort of deep_order_kernel), so
-        // this is a segmented sum.  Thread = one column (with KDIM < 256 the 256 / KDIM thread groups take one
-        // slice of the centres each); it walks the run, adds the neighbour's value (straight from global memory: a
-        // row is one coalesced read of the group) to a running sum that restarts at every change of centre, and
-        // stores the running sum to M_f[centre] after EVERY record -- the last store of a centre is its total.  No
-        // branch in the loop: selects, one fma, one 4-byte LDS store per record and thread, where the selection
-        // product S_f . rows spent 64 x KDIM x 2 matrix-core flops per record.  Exact for any values.
-        __syncthreads();                                     // previous tap's stage 2 has read A; meta free
-        for (int e = threadIdx.x; e < kGroups * 64 * LDA; e += 256) A[e] = 0.0f;
+        // this is a segmented sum: the thread walks its part of the run, adds the neighbour's values to running sums
+        // that restart at every change of centre, and stores them to M_f[centre] after EVERY record -- the last
+        // store of a centre is its total (the parts are cut at changes of centre: deep_order_kernel's tap_split).
+        // No branch per record: selects, four fmas, one 16-byte LDS store.  Exact for any values.
+        // What bounds this stage is the NUMBER of vector-memory instructions (a wave-level gather costs ~30-40 cycles
+        // of the CU's address unit whatever its width, tools/ubench/gather_rate.hip): one 16-byte load per lane
+        // fetches a record's row with KDIM / 4 lanes, i.e. 256 / KDIM records per wave instruction -- the
+        // column-per-thread layout of the first version spent 4x as many.
+        // Software pipeline over kD NAMED slots of kU records (loop unrolled by kD, all loads unconditional from
+        // clamped indices, wave-uniform control flow: see the register path's backward kernel): the metadata of
+        // step s+3 and the rows of step s+2 are in flight while step s is consumed.
+        __syncthreads();                                     // previous super-step's stage 2 has read A
+        for (int e = threadIdx.x; e < TG * 64 * LDA / 4; e += 256)
+            reinterpret_cast<float4 *>(A)[e] = make_float4(0.f, 0.f, 0.f, 0.f);   // centres without the tap stay zero
+        const int ti = t0 + gslot;
+        const uint32_t f1 = ti < nne ? taps[ti] : 0u;
+        const uint4 sp = tap_split[tile_id * (size_t)ntap + f1];
+        __syncthreads();
         {
-            // With KDIM < 256 the kGroups = 256 / KDIM threads of a column take every kGroups-th record of the run
-            // (each one's subsequence is still centre-major) and keep their partial sums in separate copies of M_f,
-            // added when stage 2 reads them: every thread has a load to issue at every step.
-            const int col = (int)threadIdx.x % KDIM, grp = (int)threadIdx.x / KDIM;
-            const bool col_ok = col < kreal;
-            const int colc = col_ok ? col : 0;
-            float *Ag = A + grp * 64 * LDA + col;
-            float *dummy = scrap + threadIdx.x;              // where the stores of steps past the run's end go
-            float sum = 0.0f;
-            uint32_t prev = 64;                              // centre of the running sum (64 = none)
-            for (uint32_t eb = e0; eb < e1; eb += kDeepBatch) {
-                if (eb != e0) __syncthreads();               // previous batch's metadata consumed
-                deep_fetch_meta(meta, eb, e1, (uint32_t)kreal, mrec);
-                __syncthreads();                             // (first batch: also orders the zeroing of A)
-                GDBG(0)
-                const uint32_t nrec = (CONV3P_ABLATE & 32768) ? 0u : min((uint32_t)kDeepBatch, e1 - eb);
-                constexpr int kU = 16;                       // records per thread and step; two steps in flight
-                // Every load of a step is UNCONDITIONAL (steps past the run's end re-read record 0, columns past the
-                // real row length re-read column 0; both are discarded by selects afterwards): with predicated loads
-                // hipcc wraps each one in its own exec-mask branch -- LDS read, wait, address, load, sixteen times in
-                // series -- and can no longer count the loads in flight, so every step drained the queue.
-                auto fetch = [&](uint32_t p0, float (&v)[kU], float (&w)[kU], uint32_t (&q)[kU]) {
-                    uint4 m[kU];
+            const uint32_t rbeg = part == 0 ? 0u : part == 1 ? sp.x : part == 2 ? sp.y : sp.z;
+            const uint32_t rend = part == 0 ? sp.x : part == 1 ? sp.y : part == 2 ? sp.z : sp.w;
+            const uint32_t len = ti < nne ? rend - rbeg : 0u;
+            const uint2 *run = meta + (ti < nne ? toff[f1] + rbeg : 0u);
+            constexpr int kU = 4, kD = 4;
+            uint2 m[kD][kU];
+            float4 v[kD][kU];
+            auto ld_meta = [&](int sl, uint32_t p0) {
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) {
-                        const uint32_t p = p0 + (uint32_t)(u * kGroups + grp);
-                        m[u] = mrec[p < nrec ? p : 0u];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);       // all 16 LDS reads issued before the first one is waited for
+                for (int u = 0; u < kU; ++u) m[sl][u] = run[p0 + u < len ? p0 + u : 0u];
+            };
+            auto ld_rows = [&](int sl) {
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) {
-                        const uint32_t p = p0 + (uint32_t)(u * kGroups + grp);
-                        q[u] = p < nrec ? m[u].y : 64u;
-                        w[u] = __builtin_bit_cast(float, m[u].z);
-                        v[u] = src_cloud[m[u].x + (uint32_t)colc];
+                for (int u = 0; u < kU; ++u) {
+                    const float *row = src_cloud + (size_t)(m[sl][u].x & 0xFFFFFFu) * kreal;
+                    if constexpr (wide) {
+                        const float4_a4 t = *reinterpret_cast<const float4_a4 *>(row + lstart);
+                        v[sl][u] = make_float4(t.x, t.y, t.z, t.w);
+                    } else {                                 // rows of 1..3 floats: clamped scalar loads
+                        v[sl][u] = make_float4(row[0], row[kreal > 1 ? 1 : 0], row[kreal > 2 ? 2 : 0], 0.f);
                     }
-                };
-                auto consume = [&](const float (&v)[kU], const float (&w)[kU], const uint32_t (&q)[kU]) {
+                }
+            };
+            float sum[4] = {0.f, 0.f, 0.f, 0.f};
+            uint32_t prev = 64;                              // centre of the running sums (64 = none)
+            // (control flow is kept WAVE-UNIFORM -- a wave holds several groups with different run lengths, the
+            // shorter ones idle on clamped loads and masked stores: with a per-lane loop exit hipcc's wait counts
+            // degenerate to draining the queue at the top of every unrolled iteration)
+            if (__any(len != 0)) {
+                ld_meta(0, 0);
+                ld_meta(1, kU);
+                ld_meta(2, 2 * kU);
+                __builtin_amdgcn_sched_barrier(0);
+                ld_rows(0);
+                ld_rows(1);
+                uint32_t p0 = 0;
+                bool more = true;
+                while (more) {
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) {
-                        const bool in = q[u] != 64u;
-                        badsum += v[u] - v[u];               // 0 for finite values, NaN otherwise (see the epilogue)
-                        const float x = col_ok ? v[u] : 0.0f;
-                        const float t = q[u] == prev ? __builtin_fmaf(x, w[u], sum) : x * w[u];
-                        sum = in ? t : sum;
-                        prev = in ? q[u] : prev;
-                        float *dst = in ? Ag + q[u] * LDA : dummy;
-                        *dst = sum;
+                    for (int j = 0; j < kD; ++j) {
+                        if (!__any(p0 < len)) {
+                            more = false;
+                            break;
+                        }
+                        ld_meta((j + 3) % kD, p0 + 3 * kU);
+                        ld_rows((j + 2) % kD);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) {
+                            const bool in = p0 + u < len;
+                            const uint32_t q = m[j][u].x >> 24;
+                            const float w = __builtin_bit_cast(float, m[j][u].y);
+                            const float4 r = v[j][u];
+                            // 0 for finite values, NaN otherwise (see the epilogue)
+                            badsum += (r.x - r.x) + (r.y - r.y) + (r.z - r.z) + (r.w - r.w);
+                            float x[4];
+                            if constexpr (wide) {
+                                const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    x[c] = 0.0f;
+#pragma unroll
+                                    for (int d = 0; d < 4; ++d)
+                                        if (d >= c) x[c] = (shl == d - c) ? rr[d] : x[c];
+                                }
+                            } else {
+                                x[0] = col0 + 0 < kreal ? r.x : 0.0f;
+                                x[1] = col0 + 1 < kreal ? r.y : 0.0f;
+                                x[2] = col0 + 2 < kreal ? r.z : 0.0f;
+                                x[3] = 0.0f;
+                            }
+                            const bool same = q == prev;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {    // (scalars: a select between float4 objects goes through scratch)
+                                const float t = same ? __builtin_fmaf(x[c], w, sum[c]) : x[c] * w;
+                                sum[c] = in ? t : sum[c];
+                            }
+                            prev = in ? q : prev;
+                            float *dst = in ? Ag + q * LDA : dummy;
+                            *reinterpret_cast<float4 *>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+                        }
+                        p0 += kU;
                     }
-                };
-                float va[kU], wa[kU], vb[kU], wb[kU];
-                uint32_t qa[kU], qb[kU];
-                constexpr uint32_t kStep = (uint32_t)(kU * kGroups);
-                fetch(0, va, wa, qa);
-                for (uint32_t p0 = 0; p0 < nrec; p0 += 2 * kStep) {
-                    fetch(p0 + kStep, vb, wb, qb);
-                    consume(va, wa, qa);
-                    fetch(p0 + 2 * kStep, va, wa, qa);
-                    consume(vb, wb, qb);
                 }
             }
         }
-#if CONV3P_ABLATE & 16777216
-        gtap++;
-#endif
-        __syncthreads();                                     // M_f complete in LDS [64][LDA]
-        // grad_input pass: M_f (= G_f' of this tile) also goes to gbuf, the grad_filter kernel's B operand
+        __syncthreads();                                     // M of the super-step's taps complete in LDS
+        GDBG(0)
+        const int ntp = nne - t0 < TG ? nne - t0 : TG;       // taps of this super-step
+        // grad_input pass: every M_f (= G_f' of this tile) also goes to gbuf, the grad_filter kernel's B operand
         if (BWD && gbuf != nullptr) {
-            float *gt = gbuf + (tile_id * (size_t)ntap + f) * 64 * KDIM;
-            for (int e = threadIdx.x; e < 64 * KDIM; e += 256) {
-                float g = A[(e / KDIM) * LDA + (e % KDIM)];
+            for (int g = 0; g < ntp; ++g) {
+                const float *Af = A + g * 64 * LDA;
+                float *gt = gbuf + (tile_id * (size_t)ntap + taps[t0 + g]) * 64 * KDIM;
+                for (int e = threadIdx.x; e < 64 * KDIM; e += 256) gt[e] = Af[(e / KDIM) * LDA + (e % KDIM)];
+            }
+        }
+        // ---- stage 2: out += M_f . Bm[f] for the super-step's taps, as ONE flat sequence of k-groups (KG MFMA
+        // k-steps each) over all of them: the B operand of group i+2 is requested before group i's MFMAs are issued
+        // (three NAMED buffers, loop unrolled by three; loads unconditional from a clamped group index) -- with one
+        // group of look-ahead and a register copy at the end, every group waited a full L2 latency for its operand.
+        if (o_on) {
+            constexpr int GPT = KDIM / (2 * KG);             // k-groups per tap
+            const int ng = ntp * GPT;
+            const float *Bl = Bm + (lane >> 5) * NDIM + cb0 * 32 + (lane & 31);
+            const float *Al = A + myrow * LDA + (lane >> 5);
+            auto load_g = [&](int gi, float (&bv)[KG][OPW]) {
+                const int gc = gi < ng ? gi : ng - 1;
+                const float *Bf = Bl + (size_t)taps[t0 + gc / GPT] * KDIM * NDIM + (size_t)(gc % GPT) * (2 * KG) * NDIM;
 #pragma unroll
-                for (int gi = 1; gi < kGroups; ++gi) g += A[gi * 64 * LDA + (e / KDIM) * LDA + (e % KDIM)];
-                gt[e] = g;
+                for (int s2 = 0; s2 < KG; ++s2)
+#pragma unroll
+                    for (int j = 0; j < OPW; ++j) bv[s2][j] = Bf[(size_t)(2 * s2) * NDIM + j * 64];
+            };
+            auto mma_g = [&](int gi, const float (&bv)[KG][OPW]) {
+                const float *arow = Al + (gi / GPT) * 64 * LDA + (gi % GPT) * (2 * KG);
+#pragma unroll
+                for (int s2 = 0; s2 < KG; ++s2) {
+                    const float a = arow[2 * s2];
+#pragma unroll
+                    for (int j = 0; j < OPW; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[s2][j], acc[j], 0, 0, 0);
+                }
+            };
+            float b0[KG][OPW], b1[KG][OPW], b2[KG][OPW];
+            load_g(0, b0);
+            load_g(1, b1);
+            for (int gi = 0; gi < ((CONV3P_ABLATE & 65536) ? 0 : ng); gi += 3) {
+                load_g(gi + 2, b2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_g(gi, b0);
+                if (gi + 1 >= ng) break;
+                load_g(gi + 3, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_g(gi + 1, b1);
+                if (gi + 2 >= ng) break;
+                load_g(gi + 4, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_g(gi + 2, b2);
             }
         }
         GDBG(4)
-        // ---- stage 2: out += M_f . Bm[f]   (B operand from L2, one group of KG k-steps ahead)
-        if (o_on) {
-            const float *Bf = Bm + (size_t)f * KDIM * NDIM + (lane >> 5) * NDIM + cb0 * 32 + (lane & 31);
-            const float *arow = A + myrow * LDA + (lane >> 5);
-            float bc[KG][OPW], bn[KG][OPW];
-            auto load_b = [&](int k0, float (&bv)[KG][OPW]) {
-#pragma unroll
-                for (int s = 0; s < KG; ++s)
-#pragma unroll
-                    for (int j = 0; j < OPW; ++j) bv[s][j] = Bf[(size_t)(k0 + 2 * s) * NDIM + j * 64];
-            };
-            load_b(0, bc);
-            for (int k0 = 0; k0 < ((CONV3P_ABLATE & 65536) ? 0 : KDIM); k0 += 2 * KG) {
-                if (k0 + 2 * KG < KDIM) load_b(k0 + 2 * KG, bn);
-#pragma unroll
-                for (int s = 0; s < KG; ++s) {
-                    float a = arow[k0 + 2 * s];
-#pragma unroll
-                    for (int gi = 1; gi < kGroups; ++gi) a += arow[gi * 64 * LDA + k0 + 2 * s];
-#pragma unroll
-                    for (int j = 0; j < OPW; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[s][j], acc[j], 0, 0, 0);
-                }
-#pragma unroll
-                for (int s = 0; s < KG; ++s)
-#pragma unroll
-                    for (int j = 0; j < OPW; ++j) bc[s][j] = bn[s][j];
-            }
-        }
     }
 
     GDBG(5)
 #if CONV3P_ABLATE & 16777216
-    if (threadIdx.x == 0 && (blockIdx.x % 400) == 100)   // developer instrumentation build only
-        printf("gemm<%d,%d,%d> dbg (10 ns ticks): taps %lld blocks %lld | meta %lld  store+sync %lld  s1-mfma %lld  sync %lld  Mf->LDS %lld  stage2(+last) %lld\n",
-               KDIM, NDIM, (int)BWD, gtap, gblk, gk[0], gk[1], gk[2], gk[3], gk[4], gk[5]);
+    if (lane == 0 && (blockIdx.x % 400) == 100)   // developer instrumentation build only
+        printf("gemm<%d,%d,%d> wg %d wave %d dbg (10 ns ticks): total %lld | stage 1 (+ barriers) %lld  gbuf + stage 2 %lld  tail %lld | taps %d\n",
+               KDIM, NDIM, (int)BWD, (int)blockIdx.x, wave, wall_clock64() - gstart, gk[0], gk[4], gk[5], nne);
 #endif
     // ---- epilogue: C fragments -> out rows (by original index)
     const bool bad = __syncthreads_or(!(badsum == 0.0f)) != 0;
