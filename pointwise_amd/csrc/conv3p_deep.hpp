@@ -347,13 +347,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
 {
     constexpr int LDA = KDIM + 4;                         // rows 16-byte aligned (stage 1 stores 4 columns at once)
     constexpr int TG = KDIM < 256 ? 256 / KDIM : 1;        // taps per super-step = thread groups of stage 1
-    // 32x32 blocks of M_f (2 x KDIM/32) and of the output (2 x NDIM/32) are dealt to the 4 waves so that every
-    // index below is a compile-time constant (accumulators stay in AGPRs, no predicated MFMAs): wave w owns the
-    // row block w & 1 and the column blocks (w >> 1) + 2j.  With a single column block (32 channels) only
-    // waves 0 and 1 take part.
+    // The 2 x NDIM/32 output blocks (32 x 32) are dealt to the 4 waves so that every index below is a compile-time
+    // constant (accumulators stay in registers, no predicated MFMAs).  With four or more column blocks a wave owns
+    // BOTH row blocks of its column blocks w, w+4, ...: every B-operand value it fetches from L2 feeds two MFMAs and
+    // no two waves fetch the same value (the filter block is re-read for every (tile, tap): 2*64*N flops per
+    // K*N*4 bytes, the stage's L2 traffic).  With two column blocks: wave = (row block w & 1, column block w >> 1);
+    // with one: waves 0 and 1 take a row block each.
     constexpr int CBK = KDIM / 32;                        // column blocks of M_f
     constexpr int CBN = NDIM / 32;                        // column blocks of the output
-    constexpr int OPW = CBN >= 2 ? CBN / 2 : 1;
+    constexpr bool kBoth = CBN >= 4;
+    constexpr int RBW = kBoth ? 2 : 1;                    // row blocks per wave
+    constexpr int CPW = kBoth ? CBN / 4 : 1;              // column blocks per wave
+    constexpr int CSTEP = kBoth ? 4 : 2;                  // distance of a wave's column blocks
+    constexpr int OPW = RBW * CPW;                        // accumulator blocks per wave
     constexpr int KG = 8;                                 // MFMA k-steps per B-operand prefetch group
     static_assert(KDIM % 32 == 0 && NDIM % 32 == 0 && KDIM <= 256 && (CBK == 1 || CBK % 2 == 0) && (CBN == 1 || CBN % 2 == 0),
                   "deep path: channel counts are 32 or multiples of 64");
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     if (tile_sched == 0xFFFFFFFFu) return;
     const int b = (int)(tile_sched / (uint32_t)ntiles), qt = (int)(tile_sched % (uint32_t)ntiles);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rb = wave & 1, cb0 = wave >> 1;             // this wave's row block and first column block
+    const int rb = kBoth ? 0 : (wave & 1), cb0 = kBoth ? wave : (wave >> 1);   // first row / column block of this wave
     const bool o_on = CBN >= 2 || wave < 2;
     const uint32_t myrow = (uint32_t)(rb * 32 + (lane & 31));
     const size_t tile_id = (size_t)b * ntiles + qt;
@@ -575,25 +581,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             const int ng = ntp * GPT;
             const float *Bl = Bm + (lane >> 5) * NDIM + cb0 * 32 + (lane & 31);
             const float *Al = A + myrow * LDA + (lane >> 5);
-            auto load_g = [&](int gi, float (&bv)[KG][OPW]) {
+            auto load_g = [&](int gi, float (&bv)[KG][CPW]) {
                 const int gc = gi < ng ? gi : ng - 1;
                 const float *Bf = Bl + (size_t)taps[t0 + gc / GPT] * KDIM * NDIM + (size_t)(gc % GPT) * (2 * KG) * NDIM;
 #pragma unroll
                 for (int s2 = 0; s2 < KG; ++s2)
 #pragma unroll
-                    for (int j = 0; j < OPW; ++j) bv[s2][j] = Bf[(size_t)(2 * s2) * NDIM + j * 64];
+                    for (int j = 0; j < CPW; ++j) bv[s2][j] = Bf[(size_t)(2 * s2) * NDIM + j * (CSTEP * 32)];
             };
-            auto mma_g = [&](int gi, const float (&bv)[KG][OPW]) {
+            auto mma_g = [&](int gi, const float (&bv)[KG][CPW]) {
                 const float *arow = Al + (gi / GPT) * 64 * LDA + (gi % GPT) * (2 * KG);
 #pragma unroll
                 for (int s2 = 0; s2 < KG; ++s2) {
-                    const float a = arow[2 * s2];
+                    float a[RBW];
 #pragma unroll
-                    for (int j = 0; j < OPW; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[s2][j], acc[j], 0, 0, 0);
+                    for (int i = 0; i < RBW; ++i) a[i] = arow[i * 32 * LDA + 2 * s2];
+#pragma unroll
+                    for (int i = 0; i < RBW; ++i)
+#pragma unroll
+                        for (int j = 0; j < CPW; ++j)
+                            acc[i * CPW + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[s2][j], acc[i * CPW + j], 0, 0, 0);
                 }
             };
-            float b0[KG][OPW], b1[KG][OPW], b2[KG][OPW];
+            float b0[KG][CPW], b1[KG][CPW], b2[KG][CPW];
             load_g(0, b0);
             load_g(1, b1);
             for (int gi = 0; gi < ((CONV3P_ABLATE & 65536) ? 0 : ng); gi += 3) {
@@ -624,14 +634,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     if (bad && threadIdx.x == 0) tile_flag[tile_id] = 1;   // zero rows now, exact accumulation by the generic kernel
     if (o_on) {
 #pragma unroll
-        for (int j = 0; j < OPW; ++j)
+        for (int i = 0; i < RBW; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int orig = qorig[row];
-                const int col = (cb0 + 2 * j) * 32 + (lane & 31);
-                if (orig >= 0 && col < nreal) out_cloud[(size_t)orig * nreal + col] = bad ? 0.0f : acc[j][r];
-            }
+            for (int j = 0; j < CPW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (rb + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int orig = qorig[row];
+                    const int col = (cb0 + CSTEP * j) * 32 + (lane & 31);
+                    if (orig >= 0 && col < nreal) out_cloud[(size_t)orig * nreal + col] = bad ? 0.0f : acc[i * CPW + j][r];
+                }
     }
 }
 
