@@ -478,7 +478,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             const uint32_t rbeg = part == 0 ? 0u : part == 1 ? sp.x : part == 2 ? sp.y : sp.z;
             const uint32_t rend = part == 0 ? sp.x : part == 1 ? sp.y : part == 2 ? sp.z : sp.w;
             const uint32_t len = ti < nne ? rend - rbeg : 0u;
-            const uint2 *run = meta + (ti < nne ? toff[f1] + rbeg : 0u);
+            // (an empty part still issues clamped loads of "its" record 0: point it at the tap's first record, which
+            // exists -- the slot after the run's end may never have been written)
+            const uint2 *run = meta + (ti < nne ? toff[f1] + (len != 0 ? rbeg : 0u) : 0u);
             constexpr int kU = 4, kD = 4;
             uint2 m[kD][kU];
             float4 v[kD][kU];

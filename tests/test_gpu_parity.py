@@ -470,10 +470,11 @@ def test_stack_with_cache_hints_over_changing_batches(dev):
 
 
 # ------------------------------------------------------------------ deep-channel (matrix-core) path
-@pytest.mark.parametrize("ci,co", [(128, 256), (64, 128), (128, 128)])
+@pytest.mark.parametrize("ci,co", [(128, 256), (64, 128), (128, 128), (3, 64), (37, 2), (7, 43)])
 def test_deep_channel_path_matches_oracle(dev, ci, co):
     """cfg5-shaped layers go through the factorised MFMA kernels (conv3p_deep.hpp); room-like data, several
-    tiles per cloud, both ops."""
+    tiles per cloud, both ops.  The odd shapes exercise the padded instantiations: rows shorter than one 16-byte
+    load (3 inputs / 2 outputs), row lengths that are not multiples of 4 (37, 7, 43)."""
     B, N = 2, 700
     P = synth.room_like(B, N, 950, extent=(1.0, 1.0, 1.5))
     X = synth.features(B, N, ci, 951, points=P)
