@@ -38,5 +38,9 @@ python $ROOT/tools/pmc_query.py $OUT/${TAG}_serial_trace/t_results.db > $OUT/${T
 python $ROOT/tools/stack_time.py > $OUT/${TAG}_stack_time.txt 2>&1
 python $ROOT/tools/f64_time.py > $OUT/${TAG}_f64_time.txt 2>&1
 python $ROOT/tools/generic_time.py > $OUT/${TAG}_generic_time.txt 2>&1
+# 6. single layers at the cfg4 cloud size (B=16, N=4096 rooms): the models' shapes on the register path, SceneNN's and
+#    other mid-size shapes on the matrix-core path
+for s in "9 9" "36 13" "36 41" "12 9" "16 16" "32 64" "64 64" "64 128"; do python $ROOT/tools/shape_time.py $s 16 4096 room 2>&1 | tail -1; done > $OUT/${TAG}_shape_time.txt
+./tools/ubench/gather_rate > $OUT/${TAG}_gather_rate.txt 2>&1 || $ROOT/tools/ubench/gather_rate > $OUT/${TAG}_gather_rate.txt 2>&1
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_serial_trace $OUT/${TAG}_pmc_*/ $OUT/${TAG}_deep_trace $OUT/${TAG}_deep_pmc   # keep the text summaries, drop the databases
 tail -c 1500 $OUT/${TAG}_bench.json; echo; head -14 $OUT/${TAG}_kernel_stats.txt; cat $OUT/${TAG}_traffic.json
