@@ -321,6 +321,15 @@ def main():
     # saves the repeats INSIDE a step (8 op calls share one `points`).  Nothing is carried across steps.
     NBATCH = 4
     Ps = [synth.modelnet_like(B_PER_GPU, N_POINTS, seed=1234 + 2 + 1000 * rank + 17 * i) for i in range(NBATCH)]
+    if os.environ.get("CONV3P_BENCH_PRESORT"):   # developer experiment: clouds arrive in Morton order (gather locality)
+        def morton(P):
+            q = np.clip(((P - P.min(axis=1, keepdims=True)) / 0.05).astype(np.int64), 0, 1023)
+            code = np.zeros(P.shape[:2], dtype=np.int64)
+            for bit in range(10):
+                for a in range(3):
+                    code |= ((q[..., a] >> bit) & 1) << (3 * bit + a)
+            return np.argsort(code, axis=1, kind="stable")
+        Ps = [np.take_along_axis(P, morton(P)[..., None], axis=1) for P in Ps]
     P = Ps[0]
     ups_np = [synth.upstream_grad(B_PER_GPU, N_POINTS, stack.HIDDEN, 77 + li + 1000 * rank) for li in range(4)]
     tPs = [torch.from_numpy(p).to(dev) for p in Ps]
