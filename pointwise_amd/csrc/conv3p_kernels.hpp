@@ -704,6 +704,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;   // uniform
     if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
+#if CONV3P_ABLATE & 134217728
+    long long ft[8];
+    int fti = 0, fsteps = 0;
+#define FDBG() { __builtin_amdgcn_s_waitcnt(0); ft[fti++] = wall_clock64(); }
+#else
+#define FDBG()
+#endif
+    FDBG()
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     // the tile's populations (tile-major copy): issued before the filter so that both are in flight together
     constexpr int kTcPer = 8;   // 27 taps x 64 centres = 1728 values: 7 per thread
@@ -739,7 +747,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const size_t tile_id = (size_t)b * ntiles + qt;
     bool overflow = false;
     for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
+    FDBG()
     __syncthreads();
+    FDBG()
     {
         // own populations -> LDS [tap][centre]; the dense small path keeps 1 / (T)count instead (the IEEE quotient,
         // .cpp:483: one division per (centre, tap) here rather than one per pair)
@@ -765,6 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         __syncthreads();
     }
 
+    FDBG()
     const T *in_cloud = input + (size_t)b * N * ld.in;
     T *out_cloud = output + (size_t)b * N * ld.out;
     T acc[kSmall ? COUT : 1];
@@ -822,10 +833,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                     const bool ok = i < sg.y && code_fwd(rec[sl].code) != kNoTap;
                     RowLoader<T, CIN>::load(in_cloud + (size_t)(ok ? rec[sl].cand : 0u) * ld.in, xs[sl]);
                 };
+                FDBG()
 #pragma unroll
                 for (int sl = 0; sl < NS - 1; ++sl) rec[sl] = ld_rec(sub + 4 * sl);
 #pragma unroll
                 for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + 4 * sl);
+                FDBG()
                 uint32_t i = sub;
                 bool more = true;
                 while (more) {
@@ -850,8 +863,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                             }
                         }
                         i += 4;
+#if CONV3P_ABLATE & 134217728
+                        fsteps++;
+#endif
                     }
                 }
+                FDBG()
             } else {
                 const uint2 sg = segs[tile_id * ngroups + g];
                 const PairEntry *pe = pairs + sg.x;
@@ -887,6 +904,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 v += __shfl_xor(v, 32);
                 if (sub == 0 && orig >= 0) out_cloud[(size_t)orig * ld.out + c] = act ? selu_value(v) : v;
             }
+#if CONV3P_ABLATE & 134217728
+            FDBG()
+            if (lane == 0 && (blockIdx.x % 211) == 7)   // developer instrumentation build only (10 ns ticks)
+                printf("fwd<%d,%d> wg %d wave %d: loads %lld sync %lld table %lld qsegs %lld first-recs %lld loop %lld (%d steps) epilogue %lld\n", CIN, COUT,
+                       (int)blockIdx.x, wave, ft[1] - ft[0], ft[2] - ft[1], ft[3] - ft[2], ft[4] - ft[3], ft[5] - ft[4], ft[6] - ft[5], fsteps, ft[7] - ft[6]);
+#endif
         } else {
             // overflow path ran lane = centre in every wave: fixed-order sum of the per-wave partial rows
 #pragma unroll
