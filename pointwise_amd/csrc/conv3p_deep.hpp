@@ -37,6 +37,7 @@
 namespace conv3p {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 4 consecutive floats of a row of `len` values starting at column `col` (zeros past the end); rows are only
 // dword-aligned in general (global_load_dwordx4 needs no more on gfx950)

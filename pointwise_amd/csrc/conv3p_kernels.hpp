@@ -14,6 +14,9 @@
 #ifndef CONV3P_ABLATE
 #define CONV3P_ABLATE 0   // developer ablation switch (tools/ablate.sh); 0 in every shipped build
 #endif
+#ifndef CONV3P_BWD_MFMA
+#define CONV3P_BWD_MFMA 1   // backward phases B and C on the matrix cores (fp32); 0: the vector-ALU version (A/B builds)
+#endif
 
 namespace conv3p {
 
@@ -1224,73 +1227,180 @@ __global__ __launch_bounds__(256) void backward_kernel(
         BDBG()
         __syncthreads();
         BDBG()
+        // (for the wide rows of the 36 -> 13 layer: backward 0.60 -> 0.37 ms at the cfg4 size; with 9 input channels
+        // the two versions take the same time, with 3 the padding to 16 columns makes the matrix version slower)
+        if constexpr (sizeof(T) == 4 && CONV3P_BWD_MFMA && CIN >= 16) {
+            // ---- phases B and C on the matrix cores (fp32: v_mfma_f32_16x16x4_f32 is an exact fmaf chain, so the
+            // results stay deterministic; only the order of the sums differs from the vector-ALU version).
+            //   B: dW[row = (f',c)][k] = sum_j G[row][j] X[j][k]      M = rows of G, N = Cin (blocks of 16), K = 64 centres
+            //   C: dX[j][k]            = sum_row G[row][j] Wt[row][k]  M = 64 centres, N = Cin, K = rows of G
+            // Operand maps (cdna_hip_programming.md section 3): A: lane l holds A[i = l & 15][k = l >> 4], B: lane l
+            // holds B[k = l >> 4][j = l & 15]; D: register r of lane l is D[row = 4 * (l >> 4) + r][col = l & 15].
+            // Rows of G past the last one are read from whatever follows G in LDS (always inside the allocation) and
+            // never stored (phase B, where output rows are independent) or zeroed by selects (phase C, where they
+            // are the contraction index).
+            constexpr int NCB = (CIN + 15) / 16;
+            const int l15 = lane & 15, l4 = lane >> 4;
+            float *slot = reinterpret_cast<float *>(partials) + (size_t)blockIdx.x * nw;
+            const float *Gf = reinterpret_cast<const float *>(G);
+            const float *xtf = reinterpret_cast<const float *>(xt);
+            const float *wtf = reinterpret_cast<const float *>(wt);
+            const int nrb = (nrows + 15) / 16;
+            for (int rb0 = wave; rb0 < ((CONV3P_ABLATE & 2) ? 0 : nrb); rb0 += 2 * kWavesPerBlock) {
+                // two row blocks at a time (independent accumulator chains): rb0 and rb0 + 4
+                const int rb1 = rb0 + kWavesPerBlock;
+                const bool two = rb1 < nrb;
+                f32x4 acc0[NCB], acc1[NCB];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    acc0[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc1[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const float *g0 = Gf + (size_t)(rb0 * 16 + l15) * kCntStride + l4;
+                const float *g1 = Gf + (size_t)((two ? rb1 : rb0) * 16 + l15) * kCntStride + l4;
+#pragma unroll 4
+                for (int j0 = 0; j0 < 64; j0 += 4) {
+                    const float a0 = g0[j0], a1 = g1[j0];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        const int n = cb * 16 + l15;
+                        float bv = xtf[(j0 + l4) * CIN + (n < CIN ? n : 0)];
+                        bv = n < CIN ? bv : 0.0f;
+                        acc0[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc0[cb], 0, 0, 0);
+                        acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc1[cb], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = cb * 16 + l15;
+                        const int row0 = rb0 * 16 + 4 * l4 + r, row1 = rb1 * 16 + 4 * l4 + r;
+                        if (n < CIN && row0 < nrows) {
+                            const int f = row0 / COUT, c = row0 - f * COUT;
+                            slot[((size_t)f * CIN + n) * COUT + c] = acc0[cb][r];
+                        }
+                        if (two && n < CIN && row1 < nrows) {
+                            const int f = row1 / COUT, c = row1 - f * COUT;
+                            slot[((size_t)f * CIN + n) * COUT + c] = acc1[cb][r];
+                        }
+                    }
+            }
+            BDBG()
+            // phase C: wave w owns the centres 16w .. 16w+15 over ALL rows: no cross-wave reduction
+            {
+                f32x4 acc0[NCB], acc1[NCB];   // even / odd k-steps: two independent chains, added at the end
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    acc0[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc1[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const int jj = wave * 16 + l15;
+                const int nr = (CONV3P_ABLATE & 4) ? 0 : nrows;
+                auto step = [&](int r0, f32x4 (&acc)[NCB]) {
+                    const int row = r0 + l4;
+                    const bool rok = row < nr;
+                    const int rc = rok ? row : 0;
+                    float av = Gf[(size_t)rc * kCntStride + jj];
+                    av = rok ? av : 0.0f;
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        const int n = cb * 16 + l15;
+                        float bv = wtf[(size_t)rc * CIN + (n < CIN ? n : 0)];
+                        bv = (rok && n < CIN) ? bv : 0.0f;
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[cb], 0, 0, 0);
+                    }
+                };
+                for (int r0 = 0; r0 < nr; r0 += 8) {
+                    step(r0, acc0);
+                    step(r0 + 4, acc1);
+                }
+                BDBG()
+                if (live) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = cb * 16 + l15;
+                            const int orig = qorig[wave * 16 + 4 * l4 + r];
+                            if (n < CIN && orig >= 0) {
+                                float sum = acc0[cb][r] + acc1[cb][r];
+                                const size_t rr = (size_t)b * N + orig;
+                                if (act) sum = (addend ? sum + addend[rr * ld.add + n] : sum) * selu_slope(input[rr * ld.in + n]);
+                                grad_input[rr * ld.dx + n] = sum;
+                            }
+                        }
+                }
+            }
+        } else {
         // ---- phase B: dW rows.  thread = row (f,c); X tile read with wave-uniform addresses.
-        T *slot = partials + (size_t)blockIdx.x * nw;
-        for (int row = threadIdx.x; row < ((CONV3P_ABLATE & 2) ? 0 : nrows); row += blockDim.x) {
-            T acc[CIN];
-#pragma unroll
-            for (int k = 0; k < CIN; ++k) acc[k] = (T)0;
-            const T *grow = G + (size_t)row * kCntStride;
-#pragma unroll 1
-            for (int j0 = 0; j0 < 64; j0 += 8) {
-                T g[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) g[u] = grow[j0 + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-#pragma unroll
-                    for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g[u], xt[(j0 + u) * CIN + k], acc[k]);
+            T *slot = partials + (size_t)blockIdx.x * nw;
+            for (int row = threadIdx.x; row < ((CONV3P_ABLATE & 2) ? 0 : nrows); row += blockDim.x) {
+                T acc[CIN];
+    #pragma unroll
+                for (int k = 0; k < CIN; ++k) acc[k] = (T)0;
+                const T *grow = G + (size_t)row * kCntStride;
+    #pragma unroll 1
+                for (int j0 = 0; j0 < 64; j0 += 8) {
+                    T g[8];
+    #pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = grow[j0 + u];
+    #pragma unroll
+                    for (int u = 0; u < 8; ++u)
+    #pragma unroll
+                        for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g[u], xt[(j0 + u) * CIN + k], acc[k]);
+                }
+                const int f = row / COUT, c = row - f * COUT;
+    #pragma unroll
+                for (int k = 0; k < CIN; ++k) slot[((size_t)f * CIN + k) * COUT + c] = acc[k];
             }
-            const int f = row / COUT, c = row - f * COUT;
-#pragma unroll
-            for (int k = 0; k < CIN; ++k) slot[((size_t)f * CIN + k) * COUT + c] = acc[k];
-        }
-        BDBG()
-        // ---- phase C: dX rows.  lane = centre j, waves split the rows.
-        T dx[CIN];
-#pragma unroll
-        for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
-        // rows are taken 4 at a time per wave so that the LDS reads of a step are independent (the loop is
-        // latency-bound at 2 waves per SIMD); summation order stays fixed: ascending row within a wave
-        {
-            constexpr int kU = 4;
-            const int nr = (CONV3P_ABLATE & 4) ? 0 : nrows;
-            int row = wave;
-            for (; row + (kU - 1) * kWavesPerBlock < nr; row += kU * kWavesPerBlock) {
-                T g[kU];
-#pragma unroll
-                for (int u = 0; u < kU; ++u) g[u] = G[(size_t)(row + u * kWavesPerBlock) * kCntStride + lane];
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const T *wr = wt + (size_t)(row + u * kWavesPerBlock) * CIN;
-#pragma unroll
-                    for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g[u], wr[k], dx[k]);
+            BDBG()
+            // ---- phase C: dX rows.  lane = centre j, waves split the rows.
+            T dx[CIN];
+    #pragma unroll
+            for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
+            // rows are taken 4 at a time per wave so that the LDS reads of a step are independent (the loop is
+            // latency-bound at 2 waves per SIMD); summation order stays fixed: ascending row within a wave
+            {
+                constexpr int kU = 4;
+                const int nr = (CONV3P_ABLATE & 4) ? 0 : nrows;
+                int row = wave;
+                for (; row + (kU - 1) * kWavesPerBlock < nr; row += kU * kWavesPerBlock) {
+                    T g[kU];
+    #pragma unroll
+                    for (int u = 0; u < kU; ++u) g[u] = G[(size_t)(row + u * kWavesPerBlock) * kCntStride + lane];
+    #pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const T *wr = wt + (size_t)(row + u * kWavesPerBlock) * CIN;
+    #pragma unroll
+                        for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g[u], wr[k], dx[k]);
+                    }
+                }
+                for (; row < nr; row += kWavesPerBlock) {
+                    const T g = G[(size_t)row * kCntStride + lane];
+                    const T *wr = wt + (size_t)row * CIN;
+    #pragma unroll
+                    for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
                 }
             }
-            for (; row < nr; row += kWavesPerBlock) {
-                const T g = G[(size_t)row * kCntStride + lane];
-                const T *wr = wt + (size_t)row * CIN;
-#pragma unroll
-                for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
-            }
-        }
-        BDBG()
-        __syncthreads();   // red aliases wt / xt: every wave is done reading them
-#pragma unroll
-        for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
-        __syncthreads();
-        if (live)
-            for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
-                const int k = e >> 6;   // e & 63 == lane
-                T sum = red[((size_t)0 * CIN + k) * 64 + lane];
-#pragma unroll
-                for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
-                if (me.idx >= 0) {
-                    const size_t r = (size_t)b * N + me.idx;
-                    if (act) sum = (addend ? sum + addend[r * ld.add + k] : sum) * selu_slope(input[r * ld.in + k]);
-                    grad_input[r * ld.dx + k] = sum;
+            BDBG()
+            __syncthreads();   // red aliases wt / xt: every wave is done reading them
+    #pragma unroll
+            for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
+            __syncthreads();
+            if (live)
+                for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
+                    const int k = e >> 6;   // e & 63 == lane
+                    T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+    #pragma unroll
+                    for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
+                    if (me.idx >= 0) {
+                        const size_t r = (size_t)b * N + me.idx;
+                        if (act) sum = (addend ? sum + addend[r * ld.add + k] : sum) * selu_slope(input[r * ld.in + k]);
+                        grad_input[r * ld.dx + k] = sum;
+                    }
                 }
-            }
+        }
 #if CONV3P_ABLATE & 33554432
         BDBG()
         if (lane == 0 && (blockIdx.x % 211) == 7)   // developer instrumentation build only (10 ns ticks)
