@@ -316,6 +316,7 @@ template <typename T> struct Call {
     // conv3p_layer_*: SELU fused into the op (pointcnn2_acsd.py:48-49).  forward: output = selu(conv);
     // backward: grad_input = (dX + addend) * selu'(input)
     bool act = false;
+    bool accum = false;            // backward: add to the grad_input already there (column-split passes)
     const T *addend = nullptr;
     RowLd ld{0, 0, 0, 0, 0};       // row strides of the feature tensors; filled with the dense values by set_ld()
     bool strided = false;          // some tensor is a column block of a wider buffer (register-path shapes only)
@@ -460,11 +461,10 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     hipLaunchKernelGGL((backward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
-                       (CI > 0 && c.act) ? 1 : 0, c.addend, gen_slots, st.window ? c.L.cmin : nullptr, c.ld);
+                       ((CI > 0 && c.act) ? 1 : 0) | ((CI > 0 && c.accum) ? 2 : 0), c.addend, gen_slots,
+                       st.window ? c.L.cmin : nullptr, c.ld);
     return hip_ok();
 }
-
-
 
 int zero_async(void *p, size_t bytes, hipStream_t s)
 {
@@ -871,6 +871,54 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
     return hip_ok();
 }
 
+// fp64 36 -> 13 (the scene_seg head in double precision): the backward kernel's G matrix (27 x 13 rows of 64 doubles)
+// plus the transposed filter do not fit LDS, and the generic kernels take 37 ms for it.  The op is linear in the
+// output channels, so it runs as three passes of the SAME register-path kernel over column blocks of 5 + 4 + 4
+// output channels: grad_out is read through its row stride from a column offset, the filter block is packed into
+// scratch, every pass adds its grad_input contribution to the previous ones (the SELU epilogue, if any, in the last
+// pass), and the grad_filter blocks are reduced and scattered back.  Deterministic like the single-pass kernel.
+template <typename T>
+int backward_split_36_13(const Call<T> &c, const T *grad_out, const T *input, const T *filter, T *grad_input,
+                         T *grad_filter)
+{
+    if constexpr (sizeof(T) != 8) {
+        return CONV3P_ERR_UNSUPPORTED;
+    } else {
+        const Dims &d = c.d;
+        const int widths[3] = {5, 4, 4};
+        const int nslots = (int)grid_of(make_blockmap(d));
+        const size_t rows = (size_t)d.ntap * d.Cin;
+        const size_t nwp_max = rows * 5;
+        T *region = c.L.partials;                         // [nslots][rows * width] per pass (sized for 13 columns)
+        T *Wp = region + (size_t)nslots * nwp_max;        // packed filter block
+        T *Wd = Wp + nwp_max;                             // its grad_filter block
+        int c0 = 0;
+        for (int p = 0; p < 3; ++p) {
+            const int cw = widths[p];
+            const size_t nwp = rows * cw;
+            hipLaunchKernelGGL(copy_cols_kernel<T>, dim3((unsigned)((nwp + 255) / 256)), dim3(256), 0, c.s, filter + c0, Wp,
+                               rows, cw, d.Cout, cw);
+            Call<T> cp = c;
+            cp.d.Cout = cw;
+            cp.accum = p > 0;
+            cp.act = c.act && p == 2;
+            cp.addend = p == 2 ? c.addend : nullptr;
+            const int rc = cw == 5 ? launch_backward<T, 36, 5>(cp, grad_out + c0, input, Wp, grad_input, region)
+                                   : launch_backward<T, 36, 4>(cp, grad_out + c0, input, Wp, grad_input, region);
+            if (rc != CONV3P_OK) return rc;
+            {
+                Scope sc(K_REDUCE, c.s);
+                hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nwp + 63) / 64)), dim3(1024), 0, c.s, region,
+                                   nslots, nwp, Wd);
+            }
+            hipLaunchKernelGGL(copy_cols_kernel<T>, dim3((unsigned)((nwp + 255) / 256)), dim3(256), 0, c.s, Wd, grad_filter + c0,
+                               rows, cw, cw, d.Cout);
+            c0 += cw;
+        }
+        return hip_ok();
+    }
+}
+
 template <typename T>
 int backward_impl(const T *grad_out, const T *points, const T *input, const T *filter,
                   const int32_t *stride, T voxel, int B, int N, int Cin, int Cout, int fz, int fy, int fx,
@@ -915,6 +963,9 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
         defer->job = ReduceJob<T>{region, grad_filter, nslots, (unsigned)nw};
         return CONV3P_OK;
     }
+    if (rc == CONV3P_ERR_UNSUPPORTED && !defer && sizeof(T) == 8 && Cin == 36 && Cout == 13 &&
+        small_shape((int)sizeof(T), Cin, Cout))
+        return backward_split_36_13<T>(c, grad_out, input, filter, grad_input, grad_filter);
     if constexpr (sizeof(T) == 4) {
         int cip = 0, cop = 0;
         if (rc == CONV3P_ERR_UNSUPPORTED && c.L.ngroups == 1 && c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {

@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     const T *__restrict__ grad_out, const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st,
     int N, int ntiles, int ngroups, int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ grad_input,
     T *__restrict__ partials, const uint8_t *__restrict__ only_flagged,
-    int act, const T *__restrict__ addend,   // act != 0 (small path only): `input` is a SELU output; store
+    int act, const T *__restrict__ addend,   // act & 1 (small path only): `input` is a SELU output; store
                                              // (dX + addend) * selu'(input), the gradient w.r.t. that SELU's argument
     int gen_slots,                           // generic path: number of grad_filter partial slots the workgroups
                                              // spread their atomics over (slot = workgroup % gen_slots)
@@ -1326,7 +1326,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
                             if (n < CIN && orig >= 0) {
                                 float sum = acc0[cb][r] + acc1[cb][r];
                                 const size_t rr = (size_t)b * N + orig;
-                                if (act) sum = (addend ? sum + addend[rr * ld.add + n] : sum) * selu_slope(input[rr * ld.in + n]);
+                                if (act & 2) sum += grad_input[rr * ld.dx + n];
+                                if (act & 1) sum = (addend ? sum + addend[rr * ld.add + n] : sum) * selu_slope(input[rr * ld.in + n]);
                                 grad_input[rr * ld.dx + n] = sum;
                             }
                         }
@@ -1396,7 +1397,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
                     if (me.idx >= 0) {
                         const size_t r = (size_t)b * N + me.idx;
-                        if (act) sum = (addend ? sum + addend[r * ld.add + k] : sum) * selu_slope(input[r * ld.in + k]);
+                        if (act & 2) sum += grad_input[r * ld.dx + k];
+                        if (act & 1) sum = (addend ? sum + addend[r * ld.add + k] : sum) * selu_slope(input[r * ld.in + k]);
                         grad_input[r * ld.dx + k] = sum;
                     }
                 }

@@ -522,7 +522,7 @@ def test_pair_buffer_overflow_falls_back_correctly(dev):
 
 # ------------------------------------------------------------------ fused conv3p + SELU layer ops
 @pytest.mark.parametrize("ci,co,dt", [(9, 9, np.float32), (3, 9, np.float32), (5, 7, np.float32), (32, 64, np.float32),
-                                      (5, 7, np.float64)])
+                                      (5, 7, np.float64), (36, 13, np.float64), (36, 13, np.float32)])
 def test_layer_ops_equal_unfused_sequence(dev, ci, co, dt):
     """conv3p_layer == selu(conv3p); conv3p_layer_grad == selu_grad(input, dX + addend), on every kernel family
     (register path, generic path, deep path, fp64)."""
@@ -544,7 +544,7 @@ def test_layer_ops_equal_unfused_sequence(dev, ci, co, dt):
         dx_ref = op.selu_grad(tX, dx_raw, a)
         dx, dw = op.conv3p_layer_grad(tdY, tP, tX, tW, s, VOX, cache, grad_addend=a)
         assert rel_err(dx.cpu().numpy(), dx_ref.cpu().numpy()) <= tol
-        if (ci, co) == (5, 7):      # generic path: global float atomics, order not fixed
+        if (ci, co) == (5, 7) and dt == np.float64:      # generic path: global float atomics, order not fixed
             assert rel_err(dw.cpu().numpy(), dw_ref.cpu().numpy()) <= 10 * tol
         else:
             assert torch.equal(dw, dw_ref)
@@ -726,15 +726,15 @@ def test_bench_prints_one_contract_json_line(dev):
 @pytest.mark.parametrize("ci,co,kind,N", [(9, 9, "modelnet", 600), (3, 9, "room", 300), (36, 13, "room", 200), (9, 3, "lattice", 256)])
 def test_fp64_register_path_matches_oracle(dev, ci, co, kind, N):
     """The reference registers T in {float, double} (register_op.cpp:44-75): the models' shapes in fp64 take the
-    same register-path kernels (templates on T; 36->13 falls back to the generic backward: its G does not fit LDS),
-    within the fp64 tolerance, and stay bitwise reproducible."""
+    same register-path kernels (templates on T; the 36->13 backward, whose G does not fit LDS in double, runs them in
+    three passes over column blocks of the output channels), within the fp64 tolerance, and stay bitwise
+    reproducible."""
     B = 2
     P, X, W, dY = make_case(kind, B, N, ci, co, seed=1100, dtype=np.float64)
     s = (2, 1, 2)
     ref = (oracle.neighbor_count(P, (3, 3, 3), s, VOX), oracle.forward(P, X, W, s, VOX)) + oracle.backward(dY, P, X, W, s, VOX)
     got = run_hip(dev, P, X, W, dY, s)
     check_against(ref, got, np.float64)
-    if (ci, co) != (36, 13):
-        again = run_hip(dev, P, X, W, dY, s)
-        for a, b in zip(got, again):
-            assert np.array_equal(a, b)
+    again = run_hip(dev, P, X, W, dY, s)
+    for a, b in zip(got, again):
+        assert np.array_equal(a, b)
