@@ -750,6 +750,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const size_t tile_id = (size_t)b * ntiles + qt;
     bool overflow = false;
     for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
+    // Dense small path: the pipeline over a centre's pair list (see the loop below) is STARTED here, before the barriers
+    // and the table of reciprocals: the list's segment, its first records and the first neighbour row are three
+    // dependent memory latencies that need nothing from LDS, so they run under the prologue instead of after it.
+#ifndef CONV3P_FWD_SLOTS
+#define CONV3P_FWD_SLOTS 3
+#endif
+    constexpr int NS = !kSmall ? 2 : sizeof(T) * CIN <= 48 ? CONV3P_FWD_SLOTS : sizeof(T) * CIN <= 144 ? 3 : 2;
+    constexpr int CINR = kSmall ? CIN : 1;
+    PairEntry rec[NS];
+    T xs[NS][CINR];
+    uint2 sg = make_uint2(0u, 0u);
+    const PairEntry *pe = pairs;
+    const T *in_cloud = input + (size_t)b * N * ld.in;
+    auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
+    auto ld_row = [&](int sl, uint32_t i) {
+        const bool ok = i < sg.y && code_fwd(rec[sl].code) != kNoTap;
+        RowLoader<T, CINR>::load(in_cloud + (size_t)(ok ? rec[sl].cand : 0u) * ld.in, xs[sl]);
+    };
+    auto start_group = [&](int g) {
+        sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
+        pe = pairs + sg.x;
+#pragma unroll
+        for (int sl = 0; sl < NS - 1; ++sl) rec[sl] = ld_rec(sub + 4 * sl);
+#pragma unroll
+        for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + 4 * sl);
+    };
+    if (kSmall && !overflow) start_group(0);
     FDBG()
     __syncthreads();
     FDBG()
@@ -779,7 +806,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     }
 
     FDBG()
-    const T *in_cloud = input + (size_t)b * N * ld.in;
     T *out_cloud = output + (size_t)b * N * ld.out;
     T acc[kSmall ? COUT : 1];
     if (kSmall) {
@@ -816,8 +842,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
             if constexpr (kSmall) {
                 // wave w owns the centres 16w..16w+15; the 4 lanes {c, c+16, c+32, c+48} share centre c and
                 // read 4 consecutive pair records per step (64 contiguous bytes)
-                const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
-                const PairEntry *pe = pairs + sg.x;
                 // Software pipeline over NS NAMED slots (the loop is unrolled by NS so that a slot is a fixed
                 // set of registers): the record of step k+2 and the neighbour row of step k+1 are in flight while
                 // step k runs its 81 FMAs.  Rotating the slots by register copies would make every step wait for
@@ -825,22 +849,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 // unconditional from clamped addresses, so hipcc can count the ones in flight.
                 // (NS = 2 for the widest rows, whose three copies would not fit the register file: the row is then
                 // loaded in the step that uses it, as before)
-#ifndef CONV3P_FWD_SLOTS
-#define CONV3P_FWD_SLOTS 3
-#endif
-                constexpr int NS = sizeof(T) * CIN <= 48 ? CONV3P_FWD_SLOTS : sizeof(T) * CIN <= 144 ? 3 : 2;
-                PairEntry rec[NS];
-                T xs[NS][CIN];
-                auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
-                auto ld_row = [&](int sl, uint32_t i) {
-                    const bool ok = i < sg.y && code_fwd(rec[sl].code) != kNoTap;
-                    RowLoader<T, CIN>::load(in_cloud + (size_t)(ok ? rec[sl].cand : 0u) * ld.in, xs[sl]);
-                };
+                if (g > 0) start_group(g);      // (group 0 was started before the barriers)
                 FDBG()
-#pragma unroll
-                for (int sl = 0; sl < NS - 1; ++sl) rec[sl] = ld_rec(sub + 4 * sl);
-#pragma unroll
-                for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + 4 * sl);
                 FDBG()
                 uint32_t i = sub;
                 bool more = true;
