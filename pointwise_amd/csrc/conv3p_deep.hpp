@@ -33,6 +33,12 @@
 #ifndef DEEP_GEMM_WAVES
 #define DEEP_GEMM_WAVES 2
 #endif
+#ifndef DEEP_KU
+#define DEEP_KU 4   // records per pipeline step of deep_gemm_kernel's stage 1
+#endif
+#ifndef DEEP_KD
+#define DEEP_KD 4   // ... and pipeline slots
+#endif
 
 namespace conv3p {
 
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             // (an empty part still issues clamped loads of "its" record 0: point it at the tap's first record, which
             // exists -- the slot after the run's end may never have been written)
             const uint2 *run = meta + (ti < nne ? toff[f1] + (len != 0 ? rbeg : 0u) : 0u);
-            constexpr int kU = 4, kD = 4;
+            constexpr int kU = DEEP_KU, kD = DEEP_KD;
             uint2 m[kD][kU];
             float4 v[kD][kU];
             auto ld_meta = [&](int sl, uint32_t p0) {
