@@ -1344,31 +1344,31 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 }
             }
         } else {
-        // ---- phase B: dW rows.  thread = row (f,c); X tile read with wave-uniform addresses.
+            // ---- phase B: dW rows.  thread = row (f,c); X tile read with wave-uniform addresses.
             T *slot = partials + (size_t)blockIdx.x * nw;
             for (int row = threadIdx.x; row < ((CONV3P_ABLATE & 2) ? 0 : nrows); row += blockDim.x) {
                 T acc[CIN];
-    #pragma unroll
+#pragma unroll
                 for (int k = 0; k < CIN; ++k) acc[k] = (T)0;
                 const T *grow = G + (size_t)row * kCntStride;
-    #pragma unroll 1
+#pragma unroll 1
                 for (int j0 = 0; j0 < 64; j0 += 8) {
                     T g[8];
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < 8; ++u) g[u] = grow[j0 + u];
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < 8; ++u)
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g[u], xt[(j0 + u) * CIN + k], acc[k]);
                 }
                 const int f = row / COUT, c = row - f * COUT;
-    #pragma unroll
+#pragma unroll
                 for (int k = 0; k < CIN; ++k) slot[((size_t)f * CIN + k) * COUT + c] = acc[k];
             }
             BDBG()
             // ---- phase C: dX rows.  lane = centre j, waves split the rows.
             T dx[CIN];
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
             // rows are taken 4 at a time per wave so that the LDS reads of a step are independent (the loop is
             // latency-bound at 2 waves per SIMD); summation order stays fixed: ascending row within a wave
@@ -1378,32 +1378,32 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 int row = wave;
                 for (; row + (kU - 1) * kWavesPerBlock < nr; row += kU * kWavesPerBlock) {
                     T g[kU];
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < kU; ++u) g[u] = G[(size_t)(row + u * kWavesPerBlock) * kCntStride + lane];
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < kU; ++u) {
                         const T *wr = wt + (size_t)(row + u * kWavesPerBlock) * CIN;
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g[u], wr[k], dx[k]);
                     }
                 }
                 for (; row < nr; row += kWavesPerBlock) {
                     const T g = G[(size_t)row * kCntStride + lane];
                     const T *wr = wt + (size_t)row * CIN;
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < CIN; ++k) dx[k] = fma_t(g, wr[k], dx[k]);
                 }
             }
             BDBG()
             __syncthreads();   // red aliases wt / xt: every wave is done reading them
-    #pragma unroll
+#pragma unroll
             for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
             __syncthreads();
             if (live)
                 for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
                     const int k = e >> 6;   // e & 63 == lane
                     T sum = red[((size_t)0 * CIN + k) * 64 + lane];
-    #pragma unroll
+#pragma unroll
                     for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
                     if (me.idx >= 0) {
                         const size_t r = (size_t)b * N + me.idx;
