@@ -27,6 +27,16 @@ Extra objects on the JSON line (rank 0; everything except `roofline` only at N=1
   stateless_ms_per_step   the same cfg2 step through the stateless C entry points exactly as the TF shim
                      (integration/tf_conv3p_shim.cc) calls them: conv3p_forward_f32 / conv3p_backward_f32 per op, no
                      cache, no hints, no prefetch, SELU as its own op -- what an unmodified TF graph would get.
+  op_boundary_cached_ms_per_step   the same 8 op calls through conv3p_forward/backward_cached_* with a persistent
+                     neighbour cache but NO caller hints and no prefetch (every call re-validates the points on the
+                     device): what a TF shim holding persistent state gets without owning the step loop.
+  valu_issue_frac    (inside roofline) per kernel: SQ_INSTS_VALU per launch (rocprofv3 PMC pass, profiles/valu_latest.json)
+                     / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction x launch duration) -- the resource the
+                     cache-resident cfg2 kernels actually load, HBM being nowhere near saturated.
+  --workload cfg5    B=16 x N=8192 clouds PER GPU, one 128->256 layer, forward+backward, one 3.54 MB all-reduce.
+  N > 1              the all-reduce runs on its own communication stream (the next step's prefetch / forward start
+                     under it), is timed with HIP events on that stream (allreduce_ms_per_step), and rccl_world is
+                     what torch.distributed reports after the first collective.
   other_configs      cfg4 (S3DIS scene_seg stack, B=16 x N=4096, 5 layers) and the cfg5 per-GPU shard (B=16 x N=8192,
                      one 128->256 layer): ms/step, Mpoints/s and a roofline each (cfg4 HBM, 1376 B/point;
                      cfg5 fp32 MFMA, USEFUL flops = 5.31 MFLOP/point = 3 x 2*27*Cin*Cout, vs 157.3 TFLOP/s).
@@ -110,6 +120,82 @@ def timed(dev, step, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+SIMDS = 1024
+CLOCK_GHZ = 2.4
+
+
+def valu_issue_fracs(kinds, steps):
+    """Per kernel: fraction of the chip's vector-issue slots its launches use (see the module docstring)."""
+    path = os.path.join(ROOT, "profiles", "valu_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    out = {}
+    for k, (n, ms) in kinds.items():
+        rec = table.get(k)
+        if not rec or not n or ms <= 0:
+            continue
+        insts = rec["SQ_INSTS_VALU"]                       # wave instructions per launch, averaged over its launches
+        slots = SIMDS * CLOCK_GHZ * 1e9 / 4.0 * (ms / n * 1e-3)
+        out[k] = {"insts_per_launch": int(insts), "avg_launch_us": round(ms / n * 1e3, 2), "frac": round(insts / slots, 4)}
+    return out
+
+
+class Reducer:
+    """The fused weight-gradient all-reduce of a step, on its own stream, timed with HIP events on that stream."""
+
+    def __init__(self, dev, world):
+        self.world = world
+        self.dev = torch.device(dev)
+        self.cuda = self.dev.type == "cuda"
+        self.stream = torch.cuda.Stream(device=dev) if world > 1 and self.cuda else None
+        self.done = None
+        self.pairs = []
+        self.host_ms = []          # CPU tensors (the gloo tests): the collective is synchronous, timed on the host
+        self.timing = False
+
+    def wait_previous(self):
+        """Before the buffer is written again (the next backward): the previous step's collective has read it."""
+        if self.done is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self.done)
+
+    def launch(self, fused):
+        if self.world == 1:
+            return
+        if not self.cuda:
+            t0 = time.perf_counter()
+            distributed.allreduce_weight_grads(fused)
+            if self.timing:
+                self.host_ms.append((time.perf_counter() - t0) * 1e3)
+            return
+        main = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            if self.timing:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(self.stream)
+            distributed.allreduce_weight_grads(fused)
+            if self.timing:
+                b.record(self.stream)
+                self.pairs.append((a, b))
+            self.done = torch.cuda.Event()
+            self.done.record(self.stream)
+
+    def finish(self):
+        if self.stream is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+    def ms_per_step(self, steps):
+        if self.host_ms:
+            return sum(self.host_ms) / steps
+        if not self.pairs:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / steps
+
+
 # ------------------------------------------------------------------------------------------- CPU legs
 def _oracle_pass(fwd, bwd, P, X, ups, filters, layers):
     acts, x = [], X
@@ -179,6 +265,26 @@ def cpu_baseline(points_np, feats_np, st, ups_np, budget_s=12.0):
             "cores": 1, "kind": "reference" if serial_ref else "port",
             "sample": "BASELINE config 1: B=1, N=2048, 3->9, stride 1, forward only, serial; best of %d calls" % n1}
     return base, cfg1, ref
+
+
+def op_boundary_cached_step(st, cache, P, X, gcat):
+    """The cfg2 step as 8 independent op calls (+ SELU ops) against ONE persistent cache: no POINTS_UNCHANGED hints,
+    no prefetch, no stack-level entry point -- the device-side validation alone decides what is rebuilt."""
+    acts, x = [], X
+    for li in range(4):
+        s_ = st.layers[li][2]
+        x = op.selu(op.conv3p(P, x, st.filters[li], (s_, s_, s_), stack.VOXEL, cache=cache))
+        acts.append(x)
+    H = stack.HIDDEN
+    carry = None
+    for li in (3, 2, 1, 0):
+        s_ = st.layers[li][2]
+        ext = gcat[:, :, H * li:H * (li + 1)].contiguous()
+        g = op.selu_grad(acts[li], ext, carry)
+        x_in = acts[li - 1] if li > 0 else X
+        carry, _ = op.conv3p_grad(g, P, x_in, st.filters[li], (s_, s_, s_), stack.VOXEL, grad_filter_out=st.grad_views[li],
+                                  cache=cache)
+    return carry
 
 
 # ------------------------------------------------------------------------------------------- other configs
@@ -296,6 +402,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip other_configs / stateless / isolated passes")
     ap.add_argument("--serial", action="store_true",
                     help="developer: no side stream at all (clean per-kernel durations under rocprofv3)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
+                    help="cfg2 (default; cfg3 at --gpus 8): B=32 x N=2048 per GPU, 4-layer stack.  cfg5: B=16 x N=8192 per "
+                         "GPU, one 128->256 layer, one 3.54 MB all-reduce")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not enqueue the next batch's neighbour search under the current batch's backward")
     args = ap.parse_args()
@@ -314,6 +423,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     lib = _lib.load()
+    if args.workload == "cfg5":
+        return main_cfg5(args, lib, dev, rank, world)
 
     # synthetic ModelNet40-shaped batches; features == points (modelnet_provider.py:212-213).
     # Every step gets a DIFFERENT batch (NBATCH distinct batches resident in HBM, cycled), as in training:
@@ -350,6 +461,8 @@ def main():
     torch.cuda.synchronize(dev)
 
     prefetch = not (args.no_prefetch or args.serial)
+    rccl_world = torch.distributed.get_world_size() if world > 1 else 1     # after the first collective (above)
+    red = Reducer(dev, world)
 
     def make_step(stk, pre):
         def step():
@@ -361,8 +474,9 @@ def main():
                 # batch's backward, as a data-loader-fed training loop would do.  Every step still performs exactly
                 # one full geometry build, one forward and one backward inside the timed region.
                 stk.prefetch(tPs[(i + 1) % NBATCH])
+            red.wait_previous()                 # the buffer the backward writes: the last all-reduce has consumed it
             dx, fused = stk.backward(gcat)
-            distributed.allreduce_weight_grads(fused)
+            red.launch(fused)                   # N > 1: on the communication stream, under the next step's forward
             return dx, fused
         return step
 
@@ -382,12 +496,18 @@ def main():
     for _ in range(args.steps):
         step()
     t_enqueued = time.perf_counter() - t0       # host side done (diagnostic: is the step host- or GPU-bound?)
+    red.finish()
     torch.cuda.synchronize(dev)
     distributed.barrier()
     elapsed = distributed.max_over_ranks(time.perf_counter() - t0, dev)
 
     # ---- per-kernel HIP-event timing of the same K steps (instrumented, not the timed region) ----
+    red.timing = True
     kinds = profile_steps(lib, dev, step, args.steps)
+    red.finish()
+    torch.cuda.synchronize(dev)
+    red.timing = False
+    allreduce_ms = red.ms_per_step(args.steps)
     extra = world == 1 and not args.no_extra
     kinds_iso = None
     if extra and prefetch:
@@ -432,6 +552,13 @@ def main():
                         "avg_launch_us_note": "measured with the headline's side-stream overlap (other kernels share "
                                               "the CUs); achieved/frac use this figure",
                         "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in kinds.items()}}
+            vf = valu_issue_fracs(kinds, args.steps)
+            if vf:
+                roofline["valu_issue_frac"] = vf
+                roofline["valu_issue_note"] = ("SQ_INSTS_VALU per launch (rocprofv3 --pmc pass of this bench, "
+                                               "profiles/valu_latest.json) / (1024 SIMDs x 2.4 GHz / 4 x launch duration "
+                                               "measured now); cfg2 is cache-resident, so this -- not HBM -- is the "
+                                               "resource its kernels load")
             if kinds_iso and dom in kinds_iso:
                 ni, msi = kinds_iso[dom]
                 roofline["avg_launch_us_isolated"] = round(msi / ni * 1e3, 2)
@@ -455,6 +582,10 @@ def main():
                           "global_batch": B_PER_GPU * world, "points_per_cloud": N_POINTS,
                           "parallelism": "dp%d" % world},
                "roofline": roofline}
+        if world > 1:
+            out["rccl_world"] = rccl_world
+            out["allreduce_ms_per_step"] = None if allreduce_ms is None else round(allreduce_ms, 4)
+            out["allreduce_bytes"] = int(st.fused_grad.numel() * 4)
         if extra:
             # the drop-in boundary as the TF shim drives it: stateless ops, SELU as separate ops
             st_plain = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, use_cache=False)
@@ -463,6 +594,18 @@ def main():
             out["stateless_ms_per_step"] = round(dt_plain * 1e3, 4)
             out["stateless_value"] = round(total_pts / dt_plain / 1e6, 3)
             del st_plain
+            # ... and through the cached entry points with a persistent cache but without any hint or prefetch
+            cache = op.NeighborCache(B_PER_GPU, N_POINTS, torch.float32, dev, slots=4, max_taps=27, max_cin=9, max_cout=9)
+            bctr = [0]
+
+            def step_boundary():
+                i = bctr[0] % NBATCH
+                bctr[0] += 1
+                return op_boundary_cached_step(st, cache, tPs[i], tXs[i], gcat)
+            dt_b = timed(dev, step_boundary, min(args.steps, 20), 3)
+            out["op_boundary_cached_ms_per_step"] = round(dt_b * 1e3, 4)
+            out["op_boundary_cached_value"] = round(total_pts / dt_b / 1e6, 3)
+            del cache
             out["other_configs"] = {"cfg4": cfg4_report(lib, dev), "cfg5_shard": cfg5_report(lib, dev),
                                     "classification_head": head_report(lib, dev)}
         if world == 1 and not args.no_cpu:
@@ -481,6 +624,73 @@ def main():
                 "max_abs_delta_dX": float(np.abs(dx.cpu().numpy() - ref_dx).max()),
                 "max_abs_delta_dW": float(np.abs(fused.cpu().numpy() - ref_fused).max()),
                 "max_abs_dW": float(np.abs(ref_fused).max())}
+        print(json.dumps(out), flush=True)
+    distributed.barrier()
+
+
+def main_cfg5(args, lib, dev, rank, world):
+    """BASELINE config 5 (per-GPU shard x world): B=16 x N=8192 SceneNN-shaped rooms per GPU, ONE 128->256 conv3p layer,
+    forward+backward, then the 884 736-float (3.54 MB) sum all-reduce of grad_filter on the communication stream."""
+    B, N, ci, co = 16, 8192, 128, 256
+    t = lambda a: torch.from_numpy(a).to(dev)
+    Ps = [t(synth.room_like(B, N, 7 + i + 1000 * rank, extent=(2.4, 2.4, 3.0))) for i in range(2)]
+    X = t(synth.features(B, N, ci, 8 + 1000 * rank, points=Ps[0].cpu().numpy()))
+    dY = t(synth.upstream_grad(B, N, co, 9 + 1000 * rank))
+    W = t(synth.filter_weights(3, 3, 3, ci, co, 5))
+    dW = torch.zeros_like(W)
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
+    distributed.allreduce_weight_grads(torch.zeros_like(dW))      # set-up: RCCL communicator
+    distributed.barrier()
+    rccl_world = torch.distributed.get_world_size() if world > 1 else 1
+    red = Reducer(dev, world)
+    ctr = [0]
+
+    def step():
+        P = Ps[ctr[0] % 2]
+        ctr[0] += 1
+        op.conv3p(P, X, W, (1, 1, 1), stack.VOXEL, cache=cache)
+        red.wait_previous()
+        op.conv3p_grad(dY, P, X, W, (1, 1, 1), stack.VOXEL, grad_filter_out=dW, cache=cache, points_unchanged=True)
+        red.launch(dW)
+
+    steps, warmup = args.steps, args.warmup
+    for _ in range(warmup):
+        step()
+    red.finish()
+    distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    red.finish()
+    torch.cuda.synchronize(dev)
+    distributed.barrier()
+    elapsed = distributed.max_over_ranks(time.perf_counter() - t0, dev)
+    red.timing = True
+    kinds = profile_steps(lib, dev, step, min(steps, 5))
+    red.finish()
+    torch.cuda.synchronize(dev)
+    allreduce_ms = red.ms_per_step(min(steps, 5))
+    if rank == 0:
+        dt = elapsed / steps
+        useful = 3 * 2 * 27 * ci * co * B * N
+        achieved = useful / dt / 1e12
+        out = {"metric": "conv3p fwd+bwd Mpoints/s", "value": round(B * N * world / dt / 1e6, 3), "unit": "Mpoints/s",
+               "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "cfg5 SceneNN-shaped: B=16 clouds/GPU x N=8192, one conv3p layer 128->256, stride 1, "
+                                      "forward+backward, geometry rebuilt every step"
+                                      + (", RCCL all-reduce of 884736 weight grads (3.54 MB) on a communication stream"
+                                         if world > 1 else ""),
+                          "global_batch": B * world, "points_per_cloud": N, "parallelism": "dp%d" % world},
+               "roofline": {"bound": "mfma", "scope": "whole step, per GPU", "achieved": round(achieved, 2),
+                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                            "flops_per_point": 3 * 2 * 27 * ci * co,
+                            "kernel_ms_per_step": {k: round(v[1] / min(steps, 5), 4) for k, v in kinds.items()}}}
+        if world > 1:
+            out["rccl_world"] = rccl_world
+            out["allreduce_ms_per_step"] = None if allreduce_ms is None else round(allreduce_ms, 4)
+            out["allreduce_bytes"] = int(dW.numel() * 4)
         print(json.dumps(out), flush=True)
     distributed.barrier()
 

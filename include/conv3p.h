@@ -289,8 +289,9 @@ int conv3p_stack_forward_f64(const conv3p_stack_desc *desc, const double *points
 /* Backward of the same stack, after conv3p_stack_forward_* on the same cache and points.
  *   grad_concat (B, N, n_hidden*hidden): gradient w.r.t. `concat` from its consumer outside the stack (the dense
  *                head of the classification model); NULL = none.
- *   grad_head   (B, N, num_class): gradient w.r.t. the head activation (num_class > 0); its contribution to the
- *                concat is added to grad_concat's.
+ *   grad_head   (B, N, num_class): gradient w.r.t. the head activation (num_class > 0).  With a head, grad_concat must
+ *                be NULL (neither model of the reference feeds the concat to a second consumer):
+ *                CONV3P_ERR_UNSUPPORTED otherwise, before anything is launched.
  *   grad_input  (B, N, in_channels); grad_filters[l] like filters[l] (e.g. views of one fused all-reduce buffer). */
 int conv3p_stack_backward_f32(const conv3p_stack_desc *desc, const float *points, const float *input,
                               const float *const *filters, float voxel_size, int B, int N, const float *concat,

@@ -14,7 +14,16 @@
 //   * `stride` and `voxel_size` are declared HostMemory on the GPU kernel, so their values are
 //     read without the blocking cudaMemcpy D2H of tf_conv3p_atrous.cu:577,586;
 //   * a shape function is attached (the reference registers none);
-//   * scratch comes from one allocate_temp per Compute (conv3p_workspace_bytes).
+//   * DEFAULT: the neighbour geometry lives in a persistent cache tensor per (device, B, N, dtype, taps) -- a
+//     process-global map, allocate_persistent, the conv3p_*_cached_* entry points WITHOUT any caller hint: every
+//     call re-validates the points on the device (content hash), so TF's buffer reuse cannot make it stale, and
+//     the 8 op calls of a model step share one sort and one search per stride instead of 8 + 8
+//     (bench.py: op_boundary_cached_ms_per_step vs stateless_ms_per_step);
+//   * -DCONV3P_SHIM_STATELESS: the stateless entry points, scratch from one allocate_temp per Compute
+//     (conv3p_workspace_bytes), nothing kept between calls.
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "tensorflow/core/framework/op.h"
 #include "tensorflow/core/framework/op_kernel.h"
 #include "tensorflow/core/framework/register_types.h"
@@ -63,12 +72,70 @@ template <> struct Abi<float> {
     static constexpr int kElem = 4;
     static constexpr auto forward = conv3p_forward_f32;
     static constexpr auto backward = conv3p_backward_f32;
+    static constexpr auto forward_cached = conv3p_forward_cached_f32;
+    static constexpr auto backward_cached = conv3p_backward_cached_f32;
 };
 template <> struct Abi<double> {
     static constexpr int kElem = 8;
     static constexpr auto forward = conv3p_forward_f64;
     static constexpr auto backward = conv3p_backward_f64;
+    static constexpr auto forward_cached = conv3p_forward_cached_f64;
+    static constexpr auto backward_cached = conv3p_backward_cached_f64;
 };
+
+#ifndef CONV3P_SHIM_STATELESS
+// One persistent neighbour cache per (device context, B, N, element size, taps): every conv3p op of a model step is
+// fed by the same points tensor (pointcnn2_acsd.py:48-66), so the ops of a step find the sort and their stride's
+// search done by the first op that needed them; a new batch changes the content hash and everything is rebuilt.
+// The cache is sized for the widest layer seen so far and re-allocated when a wider one arrives.  `mu` is held
+// across the whole C-ABI call: two Compute()s enqueueing on one stream must not interleave their kernels on the
+// same cache (they share its scratch region).
+struct CacheSlot {
+    PersistentTensor tensor;
+    size_t bytes = 0;
+    conv3p_cache_config cfg{};
+};
+typedef std::tuple<const void *, int, int, int, int> CacheKey;
+std::mutex g_cache_mu;
+std::map<CacheKey, CacheSlot> g_cache;
+
+// returns the 256-byte aligned cache buffer for this call (allocating or growing it), or nullptr with ctx failed
+char *CacheFor(OpKernelContext *ctx, int elem, int B, int N, int taps, int Cin, int Cout, CacheSlot **slot)
+{
+    const CacheKey key(ctx->op_device_context(), B, N, elem, taps);
+    CacheSlot &cs = g_cache[key];
+    if (cs.bytes == 0 || cs.cfg.max_Cin < Cin || cs.cfg.max_Cout < Cout) {
+        conv3p_cache_config cfg{};
+        cfg.slots = 8;                       // strides 1..4 of the models and room to spare (LRU beyond)
+        cfg.max_taps = taps;
+        cfg.pairs_per_point = 0;             // default capacity
+        cfg.max_Cin = Cin > cs.cfg.max_Cin ? Cin : cs.cfg.max_Cin;
+        cfg.max_Cout = Cout > cs.cfg.max_Cout ? Cout : cs.cfg.max_Cout;
+        cfg.flags = 0;                       // never CONV3P_CACHE_POINTS_UNCHANGED: TF promises nothing between ops
+        const size_t need = conv3p_cache_bytes(elem, B, N, &cfg);
+        if (need == 0) {
+            ctx->CtxFailure(errors::InvalidArgument("Conv3p: cannot size the neighbour cache"));
+            return nullptr;
+        }
+        if (cs.bytes != 0) {
+            Tensor *old = cs.tensor.AccessTensor(ctx);
+            (void)conv3p_cache_forget(old->flat<int8>().data());
+        }
+        Tensor *fresh = nullptr;
+        const Status st = ctx->allocate_persistent(DT_INT8, TensorShape({(int64)need + 256}), &cs.tensor, &fresh);
+        if (!st.ok()) {
+            cs.bytes = 0;
+            ctx->CtxFailureWithWarning(st);
+            return nullptr;
+        }
+        cs.bytes = need;                     // (uninitialised memory is fine: validity is decided by content hashes
+        cs.cfg = cfg;                        //  on the device, a garbage buffer only costs the rebuild it needs anyway)
+    }
+    *slot = &cs;
+    char *p = reinterpret_cast<char *>(cs.tensor.AccessTensor(ctx)->flat<int8>().data());
+    return p + (256 - reinterpret_cast<uintptr_t>(p) % 256) % 256;
+}
+#endif
 
 Status FromCode(int rc, const char *what)
 {
@@ -101,6 +168,16 @@ template <typename T> class Conv3pHipOp : public OpKernel {
         const int fz = filter.dim_size(0), fy = filter.dim_size(1), fx = filter.dim_size(2);
         Tensor *out = nullptr;
         OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({B, N, Cout}), &out));
+#ifndef CONV3P_SHIM_STATELESS
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        CacheSlot *cs = nullptr;
+        char *cp = CacheFor(ctx, Abi<T>::kElem, B, N, fz * fy * fx, Cin, Cout, &cs);
+        if (cp == nullptr) return;
+        const int rc = Abi<T>::forward_cached(points.flat<T>().data(), input.flat<T>().data(), filter.flat<T>().data(),
+                                              stride.flat<int32>().data() /* host memory */, voxel.flat<T>()(0), B, N,
+                                              Cin, Cout, fz, fy, fx, out->flat<T>().data(), cp, cs->bytes, &cs->cfg,
+                                              StreamOf(ctx));
+#else
         const size_t need = conv3p_workspace_bytes(CONV3P_PASS_FORWARD, Abi<T>::kElem, B, N, Cin, Cout, fz, fy, fx);
         Tensor ws;
         OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT8, TensorShape({(int64)need + 256}), &ws));
@@ -109,6 +186,7 @@ template <typename T> class Conv3pHipOp : public OpKernel {
         const int rc = Abi<T>::forward(points.flat<T>().data(), input.flat<T>().data(), filter.flat<T>().data(),
                                        stride.flat<int32>().data() /* host memory */, voxel.flat<T>()(0), B, N, Cin,
                                        Cout, fz, fy, fx, out->flat<T>().data(), wp, need, StreamOf(ctx));
+#endif
         OP_REQUIRES_OK(ctx, FromCode(rc, "Conv3p"));
     }
 };
@@ -131,6 +209,16 @@ template <typename T> class Conv3pGradHipOp : public OpKernel {
         Tensor *dx = nullptr, *dw = nullptr;
         OP_REQUIRES_OK(ctx, ctx->allocate_output(0, input.shape(), &dx));
         OP_REQUIRES_OK(ctx, ctx->allocate_output(1, filter.shape(), &dw));
+#ifndef CONV3P_SHIM_STATELESS
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        CacheSlot *cs = nullptr;
+        char *cp = CacheFor(ctx, Abi<T>::kElem, B, N, fz * fy * fx, Cin, Cout, &cs);
+        if (cp == nullptr) return;
+        const int rc = Abi<T>::backward_cached(grad.flat<T>().data(), points.flat<T>().data(), input.flat<T>().data(),
+                                               filter.flat<T>().data(), stride.flat<int32>().data(), voxel.flat<T>()(0),
+                                               B, N, Cin, Cout, fz, fy, fx, dx->flat<T>().data(), dw->flat<T>().data(), cp,
+                                               cs->bytes, &cs->cfg, StreamOf(ctx));
+#else
         const size_t need = conv3p_workspace_bytes(CONV3P_PASS_BACKWARD, Abi<T>::kElem, B, N, Cin, Cout, fz, fy, fx);
         Tensor ws;
         OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT8, TensorShape({(int64)need + 256}), &ws));
@@ -140,6 +228,7 @@ template <typename T> class Conv3pGradHipOp : public OpKernel {
                                         filter.flat<T>().data(), stride.flat<int32>().data(), voxel.flat<T>()(0), B, N,
                                         Cin, Cout, fz, fy, fx, dx->flat<T>().data(), dw->flat<T>().data(), wp, need,
                                         StreamOf(ctx));
+#endif
         OP_REQUIRES_OK(ctx, FromCode(rc, "Conv3pGrad"));
     }
 };

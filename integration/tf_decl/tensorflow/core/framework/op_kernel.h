@@ -56,11 +56,18 @@ class DeviceContext {
 };
 
 class OpKernelConstruction {};
+class OpKernelContext;
+class PersistentTensor {   // tensorflow/core/framework/op_kernel.h: a tensor that outlives one Compute()
+ public:
+    PersistentTensor();
+    Tensor *AccessTensor(OpKernelContext *context);
+};
 class OpKernelContext {
  public:
     const Tensor &input(int index);
     Status allocate_output(int index, const TensorShape &shape, Tensor **tensor);
     Status allocate_temp(DataType type, const TensorShape &shape, Tensor *out_temp);
+    Status allocate_persistent(DataType type, const TensorShape &shape, PersistentTensor *out_persistent, Tensor **out_tensor);
     DeviceContext *op_device_context();
     void CtxFailure(const Status &s);
     void CtxFailureWithWarning(const Status &s);

@@ -21,7 +21,6 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
-#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -242,8 +241,9 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
 
 inline bool small_shape(int elem, int cin, int cout)
 {
-    static const bool skip = std::getenv("CONV3P_SKIP_SMALL") != nullptr;   // developer: time the other paths on the models' shapes
-    if (skip) return false;
+#ifdef CONV3P_DEV_SKIP_SMALL   // developer build only (-DCONV3P_DEV_SKIP_SMALL): time the other paths on the models' shapes
+    return false;
+#endif
     (void)elem;   // fp32 and fp64 (the kernels are templates on T; shapes whose LDS does not fit fall back at launch)
 #define X(ci, co) if (cin == ci && cout == co) return true;
     CONV3P_SMALL_SHAPES(X)
@@ -1122,7 +1122,11 @@ int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B,
     // one_launch (prefetch of the NEXT batch: nobody waits for the first layer's lists): all strides in ONE search
     // launch, whose light tiles fill in behind another stride's heavy ones (0.534 -> 0.527 ms/step on cfg2);
     // otherwise one launch and one event per layer, so that layer 0 can start as soon as its lists exist
-    static const bool no_batch = std::getenv("CONV3P_STACK_NO_MULTI") != nullptr;   // developer A/B switch
+#ifdef CONV3P_DEV_STACK_NO_MULTI   // developer A/B build only (-DCONV3P_DEV_STACK_NO_MULTI)
+    const bool no_batch = true;
+#else
+    const bool no_batch = false;
+#endif
     if (one_launch && !no_batch && nl <= kMaxJobs) {
         int32_t strides[kMaxJobs * 3];
         int k = 0;
@@ -1250,6 +1254,7 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
     if (!points || !input || !concat || !grad_input || (has_head && (!head_out || !grad_head)) ||
         (!has_head && !grad_concat))
         return CONV3P_ERR_INVALID_ARGUMENT;
+    if (has_head && grad_concat) return CONV3P_ERR_UNSUPPORTED;   // (see conv3p.h: not needed by either model) -- before any launch
     TRY(buf_check(scratch, scratch_bytes, stack_scratch_bytes<T>(sd, B, N)));
     const size_t rows = (size_t)B * N;
     const int H = sd->hidden, CW = sd->n_hidden * H, nh = sd->n_hidden;
@@ -1297,9 +1302,6 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
         TRY(backward_impl<T>(ga, points, concat, filters[nh], sd->strides[nh], voxel, B, N, CW, sd->num_class, sd->fz,
                              sd->fy, sd->fx, dconcat, grad_filters[nh], where(), stream, false, nullptr, nullptr,
                              &red[nh]));
-        if (grad_concat) {   // both consumers: dconcat += grad_concat  (slope 1: reuse the fused add with y = +1 ...)
-            return CONV3P_ERR_UNSUPPORTED;   // not needed by either model; keep the contract honest
-        }
         ext = dconcat;
     }
     // g_l = dL/d(conv output of hidden layer l).  Last hidden layer: only the external gradient reaches its activation.
@@ -1650,6 +1652,8 @@ int conv3p_fc_backward_f32(const float *x, const float *W, const float *y, const
     TRY(buf_check(workspace, workspace_bytes, p.dz_bytes));
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *dz = static_cast<float *>(workspace);
+    const int dw_steps = M <= 32 ? 16 : M <= 64 ? 32 : 64;
+    if ((size_t)2 * dw_steps * (N + 1) * 4 > kMaxLds) return CONV3P_ERR_UNSUPPORTED;   // before anything is launched
     hipLaunchKernelGGL(fc_dz_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, y, dy, M, N, act, dz, db);
     TRY(hip_ok());
     {
@@ -1661,10 +1665,7 @@ int conv3p_fc_backward_f32(const float *x, const float *W, const float *y, const
         };
         if (M <= 32) launch(fc_dw_kernel<16>, 16);
         else if (M <= 64) launch(fc_dw_kernel<32>, 32);
-        else {
-            if ((size_t)128 * (N + 1) * 4 > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
-            launch(fc_dw_kernel<64>, 64);
-        }
+        else launch(fc_dw_kernel<64>, 64);
     }
     TRY(hip_ok());
     if (dx != nullptr) {

@@ -19,9 +19,10 @@ namespace conv3p {
 //   evaluated in double and stored as float32 (rotated_data is a float32 array, :32), the jitter is added in
 //   double (np.random.randn is float64, :73-74) and the sum becomes float32 when the batch is fed.
 //   cs[b] = {cos, sin} (host-computed, device array); cs == nullptr: no rotation; noise == nullptr: no jitter.
-__global__ __launch_bounds__(256) void augment_kernel(const float *__restrict__ in, const double2 *__restrict__ cs,
+__global__ __launch_bounds__(256) void augment_kernel(const float *in, const double2 *__restrict__ cs,
                                                       const double *__restrict__ noise, double sigma, double clip,
-                                                      float *__restrict__ out, size_t total, int N)
+                                                      float *out,   // may alias `in` (a thread reads its point before it writes it)
+                                                      size_t total, int N)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void augment_kernel(const float *__restrict__ 
 __device__ __forceinline__ uint32_t float_key(float v)
 {
     const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFEu;   // every NaN (either sign) sorts last, as numpy.argsort puts it
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 

@@ -137,14 +137,18 @@ class ClassificationHead:
         self._saved = (view, fc1, drop, mask, fc2, feat.shape)
         return fc2
 
-    def loss(self, logits, labels):
-        """mean sparse softmax cross-entropy (pointcnn2_acsd.py:79-90) and its gradient w.r.t. the logits."""
+    def loss(self, logits, labels, global_batch=None):
+        """mean sparse softmax cross-entropy (pointcnn2_acsd.py:79-90) and its gradient w.r.t. the logits.
+
+        Data parallel: pass global_batch = the batch over ALL ranks.  distributed.py reduces gradients with SUM, so the
+        gradient of the reference's mean over the global batch is each rank's dlogits / global_batch (dividing by
+        the local batch would scale every gradient by the world size).  The returned loss is the local shard's mean."""
         logp = torch.log_softmax(logits, dim=1)
         idx = labels.long().unsqueeze(1)
         e = -(logp.gather(1, idx)).mean()
         dlogits = torch.softmax(logits, dim=1)
         dlogits.scatter_add_(1, idx, -torch.ones_like(idx, dtype=dlogits.dtype))
-        return e, dlogits / logits.shape[0]
+        return e, dlogits / float(global_batch if global_batch is not None else logits.shape[0])
 
     def backward(self, dlogits):
         """-> dL/dfeat (B, N, 36); parameter gradients in self.dW1, db1, dW2, db2."""

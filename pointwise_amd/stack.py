@@ -87,9 +87,21 @@ class Conv3pStack:
         for li, (_, _, s) in enumerate(self.layers):
             for a in range(3):
                 self._desc.strides[li][a] = s
+
+    def _ptr_tables(self):
+        """Pointer tables of the stack-level C entry points, rebuilt per call: `filters[i]` may have been rebound
+        (an optimizer swap, .to())."""
         nl = len(self.layers)
-        self._fptrs = (ctypes.c_void_p * nl)(*[f.data_ptr() for f in self.filters])
-        self._gptrs = (ctypes.c_void_p * nl)(*[g.data_ptr() for g in self.grad_views])
+        for f in self.filters:
+            assert f.is_contiguous() and f.device == self.filters[0].device
+        return ((ctypes.c_void_p * nl)(*[f.data_ptr() for f in self.filters]),
+                (ctypes.c_void_p * nl)(*[g.data_ptr() for g in self.grad_views]))
+
+    def _join_side(self, device):
+        """Main stream waits for everything enqueued on the side stream: before a cache that may hold a prefetch in
+        flight is overwritten by an inline search, dropped, or handed back to the allocator."""
+        if self._side is not None:
+            torch.cuda.current_stream(device).wait_stream(self._side)
 
     # ------------------------------------------------------------------ stack-level C entry points
     def _c_call(self, name, *args):
@@ -144,7 +156,10 @@ class Conv3pStack:
                 idx = i
         if idx is None:
             idx = self._which if self._which not in self._pending else 1 - self._which
-            self._pending.pop(idx, None)       # (a prefetch that was never consumed is simply overwritten)
+            if self._pending.pop(idx, None) is not None:
+                # a prefetch that was never consumed is overwritten: its searches may still be writing this cache on
+                # the side stream, and this batch's search may run on the main stream
+                self._join_side(points.device)
         cache = self._cache_slot(idx, points)
         concat = torch.empty((B, N, HIDDEN * 4), dtype=self.dtype, device=points.device)
         head = torch.empty((B, N, self.num_class), dtype=self.dtype, device=points.device) if self.num_class else None
@@ -154,8 +169,9 @@ class Conv3pStack:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=points.device)
             side = self._side.cuda_stream
+        fptrs, _ = self._ptr_tables()
         with torch.cuda.device(points.device):
-            ok = self._c_call("forward", points.data_ptr(), features.data_ptr(), ctypes.cast(self._fptrs, ctypes.c_void_p),
+            ok = self._c_call("forward", points.data_ptr(), features.data_ptr(), ctypes.cast(fptrs, ctypes.c_void_p),
                               self._real(VOXEL), B, N, concat.data_ptr(), head.data_ptr() if head is not None else None,
                               cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(False), main.cuda_stream, side)
         if not ok:
@@ -187,13 +203,14 @@ class Conv3pStack:
             gconcat = gconcat.contiguous()
         dx = torch.empty_like(features)
         cache = self._cache
+        fptrs, gptrs = self._ptr_tables()
         with torch.cuda.device(points.device):
             ok = self._c_call("backward", points.data_ptr(), features.data_ptr(),
-                              ctypes.cast(self._fptrs, ctypes.c_void_p), self._real(VOXEL), B, N, concat.data_ptr(),
+                              ctypes.cast(fptrs, ctypes.c_void_p), self._real(VOXEL), B, N, concat.data_ptr(),
                               acts[4].data_ptr() if self.num_class else None,
                               gconcat.data_ptr() if gconcat is not None else None,
                               ghead.data_ptr() if ghead is not None else None, dx.data_ptr(),
-                              ctypes.cast(self._gptrs, ctypes.c_void_p), self._scratch.data_ptr(), self._scratch.numel(),
+                              ctypes.cast(gptrs, ctypes.c_void_p), self._scratch.data_ptr(), self._scratch.numel(),
                               cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(True),
                               torch.cuda.current_stream(points.device).cuda_stream)
         self._inflight = None
@@ -206,6 +223,10 @@ class Conv3pStack:
         cmax = max(max(ci, co) for ci, co, _ in self.layers)
         c = self._caches[idx]
         if c is None or not c.fits(B, N, points.dtype, points.device, 27, cmax, cmax):
+            if c is not None:
+                # the old buffer goes back to the allocator: nothing enqueued on the side stream may still touch it
+                self._join_side(points.device)
+                self._pending.pop(idx, None)
             c = op.NeighborCache(B, N, points.dtype, points.device, slots=len(self.layers), max_taps=27,
                                  max_cin=cmax, max_cout=cmax)
             self._caches[idx] = c

@@ -154,3 +154,77 @@ def test_sharded_weight_grads_allreduce_to_full_batch(tmp_path, B):
         got = np.load(os.path.join(str(tmp_path), "fused_%d.npy" % r))
         assert np.abs(got - full).max() <= 1e-12 * max(1.0, np.abs(full).max())
         assert float(np.load(os.path.join(str(tmp_path), "tmax_%d.npy" % r))) == 2.0
+
+
+def _bench_step_worker(rank, world, port, B, out_dir):
+    """bench.py's step assembly at world 2 on CPU tensors: shard the batch -> the shard's backward writes every
+    layer's grad_filter into the stack's grad_views -> bench.Reducer launches the ONE fused all-reduce (timed) ->
+    the JSON fields the N > 1 line carries.  Also the head's loss scaling under SUM-reduced gradients."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import json
+    import bench
+    from oracle import oracle
+    from pointwise_amd import distributed, head, stack, synth
+    distributed.init_from_env(backend="gloo")
+    st = stack.Conv3pStack(3, None, device="cpu", dtype=torch.float64, seed=21)
+    lo, hi = distributed.shard_bounds(B, world, rank)
+    P = synth.modelnet_like(B, 80, seed=90).astype(np.float64)
+    red = bench.Reducer("cpu", world)
+    red.timing = True
+    steps = 2
+    for _ in range(steps):
+        red.wait_previous()
+        for li, (ci, co, s) in enumerate(st.layers):
+            X = synth.features(B, 80, ci, 91 + li, dtype=np.float64)
+            dY = synth.upstream_grad(B, 80, co, 95 + li, dtype=np.float64)
+            _, dw = oracle.backward(dY[lo:hi], P[lo:hi], X[lo:hi], st.filters[li].numpy(), (s, s, s), 0.1)
+            st.grad_views[li].copy_(torch.from_numpy(dw))
+        red.launch(st.fused_grad)
+    red.finish()
+    fields = {"rccl_world": dist.get_world_size(), "allreduce_ms_per_step": red.ms_per_step(steps),
+              "allreduce_bytes": int(st.fused_grad.numel() * 8)}
+    json.dumps(fields)
+    np.save(os.path.join(out_dir, "bench_fused_%d.npy" % rank), st.fused_grad.numpy())
+    np.save(os.path.join(out_dir, "bench_fields_%d.npy" % rank),
+            np.asarray([fields["rccl_world"], fields["allreduce_ms_per_step"], fields["allreduce_bytes"]], dtype=np.float64))
+    # head: each rank's dlogits / GLOBAL batch, gradients summed over ranks == the full batch's mean-loss gradient
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn((B, 7), generator=g, dtype=torch.float64)
+    labels = torch.randint(0, 7, (B,), generator=g)
+    hd = head.ClassificationHead.__new__(head.ClassificationHead)      # loss() uses no state
+    _, dl = hd.loss(logits[lo:hi], labels[lo:hi], global_batch=B)
+    full = torch.zeros((B, 7), dtype=torch.float64)
+    full[lo:hi] = dl
+    dist.all_reduce(full)
+    np.save(os.path.join(out_dir, "dlogits_%d.npy" % rank), full.numpy())
+    dist.destroy_process_group()
+
+
+def test_bench_step_assembly_and_loss_scaling_at_world_2(tmp_path):
+    world, B = 2, 5
+    port = _free_port()
+    mp.spawn(_bench_step_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+    from pointwise_amd import head, stack, synth
+    st = stack.Conv3pStack(3, None, device="cpu", dtype=torch.float64, seed=21)
+    P = synth.modelnet_like(B, 80, seed=90).astype(np.float64)
+    full = []
+    for li, (ci, co, s) in enumerate(st.layers):
+        X = synth.features(B, 80, ci, 91 + li, dtype=np.float64)
+        dY = synth.upstream_grad(B, 80, co, 95 + li, dtype=np.float64)
+        full.append(oracle.backward(dY, P, X, st.filters[li].numpy(), (s, s, s), 0.1)[1].reshape(-1))
+    full = np.concatenate(full)
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn((B, 7), generator=g, dtype=torch.float64)
+    labels = torch.randint(0, 7, (B,), generator=g)
+    hd = head.ClassificationHead.__new__(head.ClassificationHead)
+    _, want_dl = hd.loss(logits, labels)                                # single process, full batch
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "bench_fused_%d.npy" % r))
+        assert np.abs(got - full).max() <= 1e-12 * max(1.0, np.abs(full).max())
+        f = np.load(os.path.join(str(tmp_path), "bench_fields_%d.npy" % r))
+        assert f[0] == world and f[1] > 0.0 and f[2] == full.size * 8
+        assert np.abs(np.load(os.path.join(str(tmp_path), "dlogits_%d.npy" % r)) - want_dl.numpy()).max() <= 1e-14

@@ -339,11 +339,12 @@ def test_scenenn_model_shapes(dev, ci, co, N):
 
 
 # ------------------------------------------------------------------ the models' layer stacks (row A8)
-def _oracle_stack(P, X, filters, layers, ups, num_class):
+def _oracle_stack(P, X, filters, layers, ups, num_class, nthreads=1):
+    fwd = lambda *a: oracle.forward(*a, nthreads=nthreads) if nthreads > 1 else oracle.forward(*a)
     acts, x = [], X
     for li in range(4):
         s = layers[li][2]
-        x = stack.selu_numpy(oracle.forward(P, x, filters[li], (s, s, s), VOX))
+        x = stack.selu_numpy(fwd(P, x, filters[li], (s, s, s), VOX))
         acts.append(x)
     dws = [None] * len(layers)
     if num_class is not None:
@@ -359,8 +360,46 @@ def _oracle_stack(P, X, filters, layers, ups, num_class):
     for li in (3, 2, 1, 0):
         s = layers[li][2]
         g = stack.selu_grad_numpy(acts[li], ext[li] if carry is None else ext[li] + carry)
-        carry, dws[li] = oracle.backward(g, P, acts[li - 1] if li > 0 else X, filters[li], (s, s, s), VOX)
+        kw = {"nthreads": nthreads} if nthreads > 1 else {}
+        carry, dws[li] = oracle.backward(g, P, acts[li - 1] if li > 0 else X, filters[li], (s, s, s), VOX, **kw)
     return acts, carry, np.concatenate([d.reshape(-1) for d in dws])
+
+
+def test_full_size_cfg2_stack_all_layers(dev):
+    """BASELINE config 2 at FULL size, the whole thing: B=32 clouds of N=2048, all four layers' activations, the
+    stack's grad_input and the fused grad_filter of all layers against the oracle stack (OpenMP over the batch).
+    grad_filter sums 65 536 points x ~10-18 pairs: its tolerance is the stated 2e-5 of max|dW| per layer."""
+    B, N = 32, 2048
+    P = synth.modelnet_like(B, N, seed=1236 + 7)
+    ups = [synth.upstream_grad(B, N, stack.HIDDEN, 77 + li) for li in range(4)]
+    st = stack.Conv3pStack(3, None, device=dev, seed=1234)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    acts = st.forward(t(P), t(P))
+    dx, fused = st.backward([t(u) for u in ups])
+    nthr = min(32, os.cpu_count() or 1)
+    ref_acts, ref_dx, ref_fused = _oracle_stack(P, P.copy(), [f.cpu().numpy() for f in st.filters], st.layers, ups, None,
+                                                nthreads=nthr)
+    for a, r in zip(acts, ref_acts):
+        assert rel_err(a.cpu().numpy(), r) <= 1e-5
+    assert rel_err(dx.cpu().numpy(), ref_dx) <= 2e-5           # four chained layers
+    got = fused.cpu().numpy()
+    o = 0
+    for f in st.filters:                                       # per layer: each has its own scale
+        n = f.numel()
+        assert rel_err(got[o:o + n], ref_fused[o:o + n]) <= 2e-5
+        o += n
+
+
+@pytest.mark.parametrize("ci,co,B,N,kind", [(32, 64, 1, 9000, "room"), (130, 20, 2, 300, "modelnet"), (200, 200, 1, 256, "cube"),
+                                            (256, 128, 1, 300, "room")])
+def test_shapes_at_the_edges_of_the_matrix_core_path(dev, ci, co, B, N, kind):
+    """A matrix-core-path shape on a cloud larger than one group of tiles (N > 8192) and layers with more than 128
+    channels other than cfg5's 128 -> 256: whatever kernel family takes them, the results are the reference's."""
+    P, X, W, dY = make_case(kind, B, N, ci, co, seed=1700 + ci + N)
+    s = (1, 1, 1)
+    ref = (oracle.neighbor_count(P, (3, 3, 3), s, VOX), oracle.forward(P, X, W, s, VOX, nthreads=8)) + \
+        oracle.backward(dY, P, X, W, s, VOX, nthreads=1)
+    check_against(ref, run_hip(dev, P, X, W, dY, s), np.float32)
 
 
 @pytest.mark.parametrize("num_class,cin,kind", [(None, 3, "modelnet"), (13, 9, "room")])

@@ -68,6 +68,64 @@ def test_fc_kernels_match_float64(dev, M, K, N, act):
 
 
 @pytest.mark.gpu
+def test_fc_kernels_match_torch_float64(dev):
+    """Second opinion on the checker itself: y = selu(x W + b) and its gradients from torch's float64 autograd on the
+    CPU (an implementation neither the kernels nor oracle/head_numpy.py share anything with)."""
+    import torch
+    from pointwise_amd import head
+    M, K, N = 32, 4096, 512
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((M, K), generator=g)
+    W = torch.randn((K, N), generator=g) / np.sqrt(K)
+    b = torch.randn((N,), generator=g) * 0.1
+    dy = torch.randn((M, N), generator=g)
+    xd, Wd, bd = (v.double().requires_grad_(True) for v in (x, W, b))
+    yd = torch.nn.functional.selu(xd @ Wd + bd)
+    yd.backward(dy.double())
+    y = head.fully_connected(x.to(dev), W.to(dev), b.to(dev), selu=True)
+    dx, dW, db = head.fully_connected_grad(x.to(dev), W.to(dev), y, dy.to(dev), selu=True)
+    assert rel(y.cpu().numpy(), yd.detach().numpy()) <= TOL
+    assert rel(dx.cpu().numpy(), xd.grad.numpy()) <= TOL and rel(dW.cpu().numpy(), Wd.grad.numpy()) <= TOL
+    assert rel(db.cpu().numpy(), bd.grad.numpy()) <= TOL
+
+
+@pytest.mark.gpu
+def test_fc_backward_says_unsupported_before_it_launches(dev):
+    """32 < M <= 64 with N = 1024: the grad-weight kernel's LDS tile does not fit; the call must say so (status
+    UNSUPPORTED) and leave the outputs untouched, not fail inside a launch after its first kernel ran."""
+    import ctypes
+    import torch
+    from pointwise_amd import _lib
+    lib = _lib.load()
+    M, K, N = 64, 256, 1024
+    x = torch.randn((M, K), device=dev)
+    W = torch.randn((K, N), device=dev)
+    y = torch.randn((M, N), device=dev)
+    dy = torch.randn((M, N), device=dev)
+    dW = torch.full((K, N), 7.0, device=dev)
+    db = torch.full((N,), 7.0, device=dev)
+    ws_bytes = lib.conv3p_fc_workspace_bytes(M, K, N)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+    rc = lib.conv3p_fc_backward_f32(x.data_ptr(), W.data_ptr(), y.data_ptr(), dy.data_ptr(), M, K, N, 1, None, dW.data_ptr(),
+                                    db.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    torch.cuda.synchronize(dev)
+    assert rc == _lib.ERR_UNSUPPORTED
+    assert float(dW.min()) == 7.0 and float(db.min()) == 7.0          # nothing ran
+    # the same M with a narrower layer is served
+    N2 = 512
+    dW2 = torch.empty((K, N2), device=dev)
+    db2 = torch.empty((N2,), device=dev)
+    ws2 = torch.empty(max(lib.conv3p_fc_workspace_bytes(M, K, N2), 256), dtype=torch.uint8, device=dev)
+    rc = lib.conv3p_fc_backward_f32(x.data_ptr(), W[:, :N2].contiguous().data_ptr(), y[:, :N2].contiguous().data_ptr(),
+                                    dy[:, :N2].contiguous().data_ptr(), M, K, N2, 0, None, dW2.data_ptr(), db2.data_ptr(),
+                                    ws2.data_ptr(), ws2.numel(), None)
+    torch.cuda.synchronize(dev)
+    assert rc == _lib.OK
+    ref_dW = x.double().T @ dy[:, :N2].double()
+    assert rel(dW2.cpu().numpy(), ref_dW.cpu().numpy()) <= TOL
+
+
+@pytest.mark.gpu
 def test_classification_head_end_to_end(dev):
     """The model's head at ModelNet size (N = 2048 -> K = 73 728, 512 hidden, 40 classes) on the conv3p stack's
     output: logits, loss and every gradient against the float64 restatement, with the dropout mask made explicit."""

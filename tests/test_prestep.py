@@ -107,6 +107,24 @@ def test_hip_sort_fresh_seeds(dev, B, N, K):
 
 
 @pytest.mark.gpu
+def test_hip_sort_puts_every_nan_last_like_numpy(dev):
+    """numpy.argsort (util.py:66-68) orders NaN after +inf whatever its sign bit; so does the key of the HIP sort."""
+    import torch
+    from pointwise_amd import prestep
+    rng = np.random.default_rng(5)
+    P = rng.uniform(-1, 1, size=(1, 64, 3)).astype(np.float32)
+    neg_nan = np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0]
+    P[0, 3, 0] = neg_nan
+    P[0, 10, 0] = np.nan
+    P[0, 20, 0] = np.inf
+    want = ref.sort_point_cloud_xyz(P)
+    got = prestep.sort_point_cloud_xyz(torch.from_numpy(P).to(dev)).cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.nan_to_num(got, nan=123.0), np.nan_to_num(want, nan=123.0))
+    assert np.isnan(got[0, -1, 0]) and np.isnan(got[0, -2, 0]) and np.isinf(got[0, -3, 0])
+
+
+@pytest.mark.gpu
 def test_hip_prestep_rejects_bad_input(dev):
     import torch
     from pointwise_amd import prestep
