@@ -173,6 +173,7 @@ template <typename T> struct Layout {
         unsigned long long *built_tag;
         int32_t *count, *tcount;   // populations: original-index order (B,N,F) / tile-major [tile][F][64]
         uint2 *segs, *qsegs;
+        uint32_t *qbm;             // [B][ntiles][64] backward taps each centre's list holds (bit f'; <= 32 taps)
         PairEntry *pairs;
     };
     std::vector<Slot> slot;
@@ -226,6 +227,7 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
         S.tcount = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)B * ntiles * kTile * ntap_max));
         S.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups));
         S.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups * 64));
+        S.qbm = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * ntiles * 64));
         S.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * (size_t)B * ppc));
     }
     L.partials = reinterpret_cast<T *>(take(scratch_bytes));
@@ -411,7 +413,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes, st, d.N, d.ntiles,
                                c.L.gtiles, c.L.ngroups, bm, count, with_pairs ? S.pairs : nullptr, c.cc, S.segs, S.qsegs,
-                               cmin, with_pairs ? S.tcount : nullptr);
+                               cmin, with_pairs ? S.tcount : nullptr, with_pairs ? S.qbm : nullptr);
         };
         if (st.window) launch(search_kernel<T, true>, c.L.cmin);
         else launch(search_kernel<T, false>, static_cast<const T *>(nullptr));
@@ -440,6 +442,29 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
     return hip_ok();
 }
 
+// Rows of the populated-rows G matrix (conv3p_backward_sparse.hpp) that fit LDS next to the kernel's other arrays with
+// four (else three, else two) workgroups per CU; 0: use backward_kernel's dense G.
+template <typename T> int sparse_cap(const Stencil<T> &st, int cin, int cout, size_t &lds)
+{
+    if (st.ntap > 32 || cin >= 16 || cin < 1 || cout < 1) return 0;   // (>= 16 inputs: the dense kernel's matrix-core phases)
+    // Undilated stencils populate a third of a centre's taps and more (adjacent cells: 9 of 27 on the ModelNet-shaped
+    // clouds, 650-850 rows per tile): their tiles would take two rounds, each walking the pair lists again
+    // (measured: 3 -> 9 stride 1 at the cfg2 size 63.8 us against 49.5 us dense).  Dilated ones: 210-450 rows.
+    if (st.step[0] * st.step[1] * st.step[2] == 1) return 0;
+    const size_t fixed = sparse_fixed_lds<T>(st.maxfull, st.ntap, cin, cout) + 64;
+    const size_t budgets[3] = {40960, 54608, 81920};
+    for (size_t bud : budgets) {
+        if (bud <= fixed) continue;
+        long long cap = (long long)((bud - fixed) / ((size_t)cout * sizeof(T)));
+        if (cap > 64LL * st.ntap) cap = 64LL * st.ntap;
+        if (cap >= 256 || cap == 64LL * st.ntap) {
+            lds = fixed + (size_t)cap * cout * sizeof(T);
+            return (int)cap;
+        }
+    }
+    return 0;
+}
+
 template <typename T, int CI, int CO>
 int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T *filter, T *grad_input,
                     T *partials = nullptr, const uint8_t *only_flagged = nullptr, int gen_slots = 1)
@@ -448,6 +473,23 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
+#ifndef CONV3P_DEV_DENSE_BACKWARD   // developer A/B build: always the dense-G kernel
+    if constexpr (CI > 0 && CI < 16) {
+        size_t slds = 0;
+        const int cap = only_flagged == nullptr ? sparse_cap<T>(st, CI, CO, slds) : 0;
+        if (cap > 0) {
+            const BlockMap bm = make_blockmap(d);
+            Scope sc(K_BACKWARD, c.s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_sparse_kernel<T, CI, CO>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+            hipLaunchKernelGGL((backward_sparse_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), slds, c.s, c.L.pts, c.L.boxes,
+                               S.count, S.pairs, S.segs, S.qsegs, S.qbm, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
+                               bm, grad_input, partials ? partials : c.L.partials, (c.act ? 1 : 0) | (c.accum ? 2 : 0), c.addend,
+                               st.window ? c.L.cmin : nullptr, c.ld, cap);
+            return hip_ok();
+        }
+    }
+#endif
     // reduce buffer [4][CI][64] aliases { Wt | X tile | SoA }
     size_t tail = (CI > 0 ? a16(nw * sizeof(T)) + a16((size_t)64 * CI * sizeof(T)) : 0) + a16((size_t)kWavesPerBlock * 192 * 4);
     const size_t red = CI > 0 ? a16((size_t)kWavesPerBlock * CI * 64 * sizeof(T)) : 0;
@@ -855,6 +897,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         j.pairs = S.pairs;
         j.segs = S.segs;
         j.qsegs = S.qsegs;
+        j.qbm = S.qbm;
     }
     if (njobs == 0) return CONV3P_OK;
     const BlockMap bm = make_blockmap(c.d);

@@ -1,0 +1,415 @@
+// conv3p_backward_sparse.hpp -- Conv3pGrad accumulate (tf_conv3p_atrous.cpp:608-716) for the models' narrow layers, with the
+// per-tile G matrix kept only where it is populated.
+//
+// backward_kernel (conv3p_kernels.hpp) builds G[(f', c)][j] = sum over the pairs (j, ii) with backward tap f' of
+// dY[ii, c] / count dense: 27 taps x Cout rows x 64 centres = 63 KiB for 9 output channels, which allows two workgroups
+// per CU -- 1 024 query tiles then run in two resident rounds and never share a CU with the next batch's search
+// (35 KiB per workgroup) running beside them.  A centre only has pairs in the taps its neighbourhood populates:
+// 9 of 27 at stride 1, 3-5 at strides 2-4.  Here G holds one row of Cout values per POPULATED
+// (centre, tap) only:
+//     slot(j, f') = tapbase[f'] + |{ centres j' < j of the tile with tap f' }|        (tap-major, centres ascending)
+// from the per-centre sets of backward taps the search leaves in `qbm` (search_tile).  With 9 -> 9 channels: ~390 / 260 /
+// 190 slots at strides 2 / 3 / 4 instead of 1 728, 37 KiB of LDS in all: FOUR workgroups per CU, one resident round.
+//   prologue  tapmask[f'] (64-bit set of centres) by ballots over the centres' masks; taps are dealt to ROUNDS whose
+//             slots fit the LDS capacity (one round for the models' strides >= 2; dense stride-1 tiles take two)
+//   phase A   the centre-major walk of backward_kernel (4 sub-lanes per centre, records 3 / rows 2 steps ahead in
+//             named register slots, equal-tap sub-lanes merged by lane swaps), RMW into G[slot][c]
+//   phase B   thread = (f', c): dW[f', k, c] = sum over the tap's slots of G[slot][c] * X[j][k]   (slots of a tap are
+//             consecutive, its centres the set bits of tapmask[f'])  -> this workgroup's partial
+//   phase C   lane = centre, waves split the taps: dX[j, k] += sum_c G[slot(j, f')][c] * W[f', k, c]; accumulated in
+//             registers across rounds, per-wave partial rows summed through LDS in fixed order
+// No floating-point atomics: bitwise reproducible.  A tile whose pair segment overflowed searches itself (as in
+// backward_kernel); its slots come from the same masks (the search computes them for such tiles too).
+#pragma once
+
+#ifndef CONV3P_SP_ABLATE
+#define CONV3P_SP_ABLATE 0   // developer ablation switch (tools/ablate_sparse.sh); 0 in every shipped build
+#endif
+
+namespace conv3p {
+
+struct __attribute__((aligned(16))) TapInfo {
+    uint32_t mask_lo, mask_hi;   // centres of the tile that have this backward tap
+    uint32_t base;               // first row of G of the tap inside its round
+    uint32_t gbase;              // first entry of the tap in the slot -> centre map (all rounds)
+};
+
+// LDS of the sparse kernel apart from G [cap][Cout]:
+// tapmap | tapinfo[32] | rounds | qorig | slot -> centre map u8[64 * 32] | rinv | { wt | xt | soa } (red aliases {})
+template <typename T> __host__ __device__ inline size_t sparse_fixed_lds(int maxfull, int ntap, int cin, int cout)
+{
+    const size_t tail0 = (((size_t)ntap * cin * cout * sizeof(T) + 15) & ~(size_t)15) + (((size_t)64 * cin * sizeof(T) + 15) & ~(size_t)15) +
+                         (size_t)kWavesPerBlock * 192 * 4;
+    const size_t red = ((size_t)kWavesPerBlock * cin * 64 * sizeof(T) + 15) & ~(size_t)15;
+    return (((size_t)3 * maxfull * 2 + 15) & ~(size_t)15) + 32 * sizeof(TapInfo) + 64 * 4 + 256 + 2048 +
+           ((256 * sizeof(T) + 15) & ~(size_t)15) + (tail0 > red ? tail0 : red);
+}
+
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void backward_sparse_kernel(
+    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
+    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
+    const uint32_t *__restrict__ qbm, const T *__restrict__ grad_out, const T *__restrict__ input,
+    const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, BlockMap bm, T *__restrict__ grad_input,
+    T *__restrict__ partials, int act, const T *__restrict__ addend, const T *__restrict__ cmin, RowLd ld,
+    int cap)   // G rows (slots) the LDS allocation holds; >= 64, so every tap fits a round of its own
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
+    size_t off = align16((size_t)3 * st.maxfull * 2);
+    TapInfo *tapinfo = reinterpret_cast<TapInfo *>(smem + off);
+    off += 32 * sizeof(TapInfo);
+    uint32_t *rinfo = reinterpret_cast<uint32_t *>(smem + off);   // [0] rounds, [1 + r] first tap of round r, ... (<= 33 entries)
+    off += 64 * 4;
+    int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
+    off += 256;
+    uint8_t *sj = reinterpret_cast<uint8_t *>(smem + off);        // centre of every (tap, slot), taps ascending
+    off += 2048;
+    T *rinv = reinterpret_cast<T *>(smem + off);                  // rinv[n] = 1 / (T)n for n < 256
+    off += align16(256 * sizeof(T));
+    const size_t nw = (size_t)st.ntap * CIN * COUT;
+    T *red = reinterpret_cast<T *>(smem + off);                   // [4][CIN][64]: ALIASES wt | xt | soa (used after them)
+    T *wt = reinterpret_cast<T *>(smem + off);                    // W[f][k][c] as stored by the caller
+    size_t off2 = off + align16(nw * sizeof(T));
+    T *xt = reinterpret_cast<T *>(smem + off2);                   // X tile [64][CIN]
+    off2 += align16((size_t)64 * CIN * sizeof(T));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *soa = reinterpret_cast<float *>(smem + off2) + wave * 192;
+    off2 += align16((size_t)kWavesPerBlock * 192 * 4);
+    const size_t redb = align16((size_t)kWavesPerBlock * CIN * 64 * sizeof(T));
+    off += off2 - off > redb ? off2 - off : redb;
+    T *G = reinterpret_cast<T *>(smem + off);                     // [cap][COUT]
+    const int cq = wave * 16 + (lane & 15), sub = lane >> 4;
+
+    build_tapmap(tapmap, st.full, st.step, st.maxfull);
+    // filter -> LDS as it is (phase B needs no transposed copy; phase C reads W[f][k][c] with a wave-uniform f)
+    for (uint32_t e0 = threadIdx.x; e0 < (uint32_t)nw; e0 += 8 * 256) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = filter[e0 + u * 256 < (uint32_t)nw ? e0 + u * 256 : 0u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * 256 < (uint32_t)nw) wt[e0 + u * 256] = v[u];
+    }
+    rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
+
+    int b, qt;
+    const bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
+    const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
+    PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
+    if (!live) me.idx = -1;
+    const size_t tile_id = (size_t)(live ? b : 0) * ntiles + (live ? qt : 0);
+    // loads that need nothing from LDS go out now, under the prologue: the tile's tap sets, its segment records (is
+    // the tile's pair list complete?), this lane's centre segment and the first records of its list
+    const uint32_t bm_raw = qbm[tile_id * 64 + lane];
+    bool overflow = false;
+    for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
+    const uint2 sg0 = qsegs[(tile_id * ngroups) * 64 + cq];
+    PairEntry rec0[3];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        const uint32_t i0 = (uint32_t)(sub + 4 * sl);
+        rec0[sl] = pairs[sg0.x + (i0 < sg0.y && sg0.y != kSegOverflow ? i0 : 0u)];
+    }
+    if (wave == 0) {
+        qorig[lane] = me.idx;
+        const T *xr = input + ((size_t)(live ? b : 0) * N + (me.idx < 0 ? 0 : me.idx)) * ld.in;
+        T xv[CIN];
+        RowLoader<T, CIN>::load(xr, xv);
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) xt[lane * CIN + k] = me.idx >= 0 ? xv[k] : (T)0;
+    }
+    // ---- which (centre, tap) rows exist, and in which round each tap is handled.  Every wave runs the same scalar
+    // bookkeeping over all taps (ballots + counts) and publishes the taps f == wave (mod 4): no serial section.
+    const uint32_t mybm = live && me.idx >= 0 ? bm_raw : 0u;   // lane = centre in every wave
+    {
+        uint32_t base = 0, gbase = 0, nrounds = 1;
+        for (int f = 0; f < st.ntap; ++f) {   // (ntap <= 32: host)
+            const bool has = (mybm >> f) & 1u;
+            const uint64_t m = __ballot(has);
+            const uint32_t n = (uint32_t)__popcll(m);
+            if (base + n > (uint32_t)cap) {
+                if (threadIdx.x == 0) rinfo[1 + nrounds] = (uint32_t)f;
+                ++nrounds;
+                base = 0;
+            }
+            if ((f & (kWavesPerBlock - 1)) == wave) {
+                if (lane == 0) {
+                    TapInfo ti;
+                    ti.mask_lo = (uint32_t)m;
+                    ti.mask_hi = (uint32_t)(m >> 32);
+                    ti.base = base;
+                    ti.gbase = gbase;
+                    tapinfo[f] = ti;
+                }
+                if (has) sj[gbase + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (uint8_t)lane;
+            }
+            base += n;
+            gbase += n;
+        }
+        if (threadIdx.x == 0) {
+            rinfo[0] = nrounds;
+            rinfo[1] = 0;
+            rinfo[1 + nrounds] = (uint32_t)st.ntap;
+        }
+    }
+    __syncthreads();
+    if (!live) {   // (uniform) a workgroup past the last cloud: its grad_filter partial is summed like the others
+        T *z = partials + (size_t)blockIdx.x * nw;
+        for (uint32_t e = threadIdx.x; e < (uint32_t)nw; e += blockDim.x) z[e] = (T)0;
+        return;
+    }
+
+    const int32_t *cnt_cloud = count + (size_t)b * N * st.ntap;
+    const T *dy_cloud = grad_out + (size_t)b * N * ld.dy;
+    T *dx_cloud = grad_input + (size_t)b * N * ld.dx;
+    const uint64_t lt_cq = cq == 0 ? 0ull : (~0ull >> (64 - cq));
+    const int orig_lane = me.idx;   // (the rest of `me` is only needed by the overflow path, which reloads it)
+    const int nrounds = (int)rinfo[0];
+    // row of G for (centre of this lane, backward tap fb); fb must belong to the running round
+    auto slot_of = [&](uint32_t fb, uint64_t lower) {
+        const TapInfo ti = tapinfo[fb];
+        const uint64_t m = ((uint64_t)ti.mask_hi << 32) | ti.mask_lo;
+        return ti.base + (uint32_t)__popcll(m & lower);
+    };
+    auto zero_G = [&](int t1) {
+        // G = 0 for the round's slots
+        {
+            const TapInfo last = tapinfo[t1 - 1];
+            const int used = (int)last.base + __popc(last.mask_lo) + __popc(last.mask_hi);
+            float4 *G4 = reinterpret_cast<float4 *>(G);
+            const int n4 = (int)(((size_t)used * COUT * sizeof(T) + 15) / 16);
+            for (int e = threadIdx.x; e < n4; e += blockDim.x) G4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto phase_A = [&](int t0, int t1) {
+        // ---- phase A
+        if (CONV3P_SP_ABLATE & 1) {
+        } else if (!overflow) {
+            for (int g = 0; g < ngroups; ++g) {
+                const uint2 sg = g == 0 ? sg0 : qsegs[(tile_id * ngroups + g) * 64 + cq];
+                const PairEntry *pe = pairs + sg.x;
+                auto live_rec = [&](const PairEntry &rc, uint32_t i) {
+                    const uint32_t fb = code_bwd(rc.code);
+                    return i < sg.y && code_fwd(rc.code) != kNoTap && fb != kNoTap && (int)fb >= t0 && (int)fb < t1;
+                };
+                constexpr int kDepth = 3;
+                PairEntry rec[kDepth];
+                bool lv[kDepth];
+                int cn[kDepth];
+                uint32_t row[kDepth];   // G row of the record's (centre, tap): looked up when the record arrives
+                T val[kDepth][COUT];
+                auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
+                auto gather = [&](int sl, uint32_t i) {
+                    lv[sl] = live_rec(rec[sl], i);
+                    row[sl] = slot_of(lv[sl] ? code_bwd(rec[sl].code) : (uint32_t)t0, lt_cq);
+                    cn[sl] = cnt_cloud[lv[sl] ? (size_t)rec[sl].cand * st.ntap + code_bwd(rec[sl].code) : (size_t)0];
+                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy, val[sl]);
+                };
+#pragma unroll
+                for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = g == 0 ? rec0[sl] : ld_rec(sub + 4 * sl);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, sub + 4 * sl);
+                uint32_t i = sub;
+                bool more = true;
+                while (more) {
+#pragma unroll
+                    for (int j = 0; j < kDepth; ++j) {
+                        if (!__any(i < sg.y)) {
+                            more = false;
+                            break;
+                        }
+                        rec[(j + kDepth - 1) % kDepth] = ld_rec(i + 4 * (kDepth - 1));
+                        gather((j + kDepth - 2) % kDepth, i + 4 * (kDepth - 2));
+                        __builtin_amdgcn_sched_barrier(0);
+                        bool pending = lv[j] & (cn[j] != 0);                                   // .cpp:679
+                        const uint32_t fb = code_bwd(rec[j].code);
+                        T(&v)[COUT] = val[j];
+                        if (pending) {
+                            const T rcpb = cn[j] < 256 ? rinv[cn[j]] : (T)1 / (T)cn[j];        // .cpp:692, :696
+#pragma unroll
+                            for (int c = 0; c < COUT; ++c) v[c] *= rcpb;
+                        }
+                        // sub-lanes of one centre that meet on a tap: the lower one absorbs the higher (fixed order)
+#pragma unroll
+                        for (int step = 0; step < 3; ++step) {
+                            const uint32_t mine_fb = pending ? fb : kNoTap;
+                            uint32_t pfb;
+                            bool lower;
+                            if (step == 0) { pfb = lane_xor16(mine_fb); lower = (sub & 1) == 0; }
+                            else if (step == 1) { pfb = lane_xor32(mine_fb); lower = sub < 2; }
+                            else { pfb = lane_xor32(lane_xor16(mine_fb)); lower = sub < 2; }
+                            const bool same = pending && pfb == fb;
+                            if (__any(same)) {
+#pragma unroll
+                                for (int c = 0; c < COUT; ++c) {
+                                    const T pv = step == 0 ? lane_xor16(v[c])
+                                               : step == 1 ? lane_xor32(v[c]) : lane_xor32(lane_xor16(v[c]));
+                                    if (same && lower) v[c] += pv;
+                                }
+                                if (same && !lower) pending = false;
+                            }
+                        }
+                        if (pending) {
+                            T *grow = G + (size_t)row[j] * COUT;
+#pragma unroll
+                            for (int c = 0; c < COUT; ++c) grow[c] += v[c];
+                        }
+                        i += 4;
+                    }
+                }
+            }
+        } else {
+            // pair buffer was full for this tile: search it here, lane = centre.  Every wave walks all candidate
+            // tiles and keeps the taps f' == wave (mod 4): one writer per row of G.
+            const T *cloud_box = boxes + (size_t)b * ntiles * 6;
+            const PointRec<T> mine = cloud_pts[(size_t)qt * kTile + lane];
+            const uint64_t lt_lane = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+            Query<T> q;
+            make_query(q, mine, st);
+            Window<T> win;
+            if (cmin != nullptr) make_window(win, mine, st, cmin + (size_t)b * 3);
+            for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, 0, 1, [&](const PointRec<T> &v, int) {
+                const uint32_t fb = backward_tap(q.p, v, st, tapmap);
+                if (fb == kNoTap || (int)(fb & (kWavesPerBlock - 1)) != wave || (int)fb < t0 || (int)fb >= t1) return;
+                const int cn = cnt_cloud[(size_t)v.idx * st.ntap + fb];
+                if (cn == 0) return;                                                           // .cpp:679
+                const T rcp = (T)1 / (T)cn;
+                const T *dyr = dy_cloud + (size_t)v.idx * ld.dy;
+                T *grow = G + (size_t)slot_of(fb, lt_lane) * COUT;
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) grow[c] += dyr[c] * rcp;
+            }, cmin != nullptr ? &win : nullptr);
+        }
+    };
+    auto phase_B = [&](int t0, int t1) {
+        T *slot_out = partials + (size_t)blockIdx.x * nw;
+        // ---- phase B: dW[f'][k][c] = sum over the tap's slots of X[j(slot)][k] * G[slot][c].  fp32: on the matrix cores
+        // (v_mfma_f32_16x16x4_f32, an exact fmaf chain: deterministic), wave w takes the round's taps f' == w (mod 4);
+        // K = the tap's slots, four per step: A[i][kk] = X[j][i], B[kk][n] = G[slot][n], D[k][c] in registers over the tap.
+        if (CONV3P_SP_ABLATE & 2) {
+        } else if constexpr (sizeof(T) == 4) {
+            const int l15 = lane & 15, l4 = lane >> 4;
+            const float *Gf = reinterpret_cast<const float *>(G);
+            const float *xtf = reinterpret_cast<const float *>(xt);
+            float *so = reinterpret_cast<float *>(slot_out);
+            for (int f = t0 + ((wave - t0) & (kWavesPerBlock - 1)); f < t1; f += kWavesPerBlock) {
+                const TapInfo ti = tapinfo[f];
+                const int n = __popc(ti.mask_lo) + __popc(ti.mask_hi);
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int s0 = 0; s0 < n; s0 += 16) {   // four steps (16 slots) per iteration: loads first, then the products
+                    int cj[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int sl = s0 + 4 * u + l4;
+                        ok[u] = sl < n;
+                        cj[u] = sj[ti.gbase + (ok[u] ? sl : 0)];
+                    }
+                    float av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int sl = ti.base + (ok[u] ? s0 + 4 * u + l4 : 0);
+                        av[u] = xtf[cj[u] * CIN + (l15 < CIN ? l15 : 0)];
+                        bv[u] = Gf[(size_t)sl * COUT + (l15 < COUT ? l15 : 0)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float a = (ok[u] && l15 < CIN) ? av[u] : 0.0f, bb = (ok[u] && l15 < COUT) ? bv[u] : 0.0f;
+                        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc1, 0, 0, 0);
+                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc0, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int k = 4 * l4 + rr;
+                    if (k < CIN && l15 < COUT) so[((size_t)f * CIN + k) * COUT + l15] = acc0[rr] + acc1[rr];
+                }
+            }
+        } else {
+            for (int row = t0 * COUT + (int)threadIdx.x; row < t1 * COUT; row += blockDim.x) {
+                const int f = row / COUT, c = row - f * COUT;
+                const TapInfo ti = tapinfo[f];
+                uint64_t m = ((uint64_t)ti.mask_hi << 32) | ti.mask_lo;
+                const T *gp = G + (size_t)ti.base * COUT + c;
+                T acc[CIN];
+#pragma unroll
+                for (int k = 0; k < CIN; ++k) acc[k] = (T)0;
+                while (m != 0) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const T g = *gp;
+                    gp += COUT;
+#pragma unroll
+                    for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g, xt[j * CIN + k], acc[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < CIN; ++k) slot_out[((size_t)f * CIN + k) * COUT + c] = acc[k];
+            }
+        }
+    };
+    auto phase_C = [&](int t0, int t1, T (&dx)[CIN]) {
+        const uint64_t lt_lane = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        // ---- phase C: lane = centre, wave w takes the round's taps f' == w (mod 4)
+        {
+            for (int f = t0 + ((wave - t0) & (kWavesPerBlock - 1)); f < ((CONV3P_SP_ABLATE & 4) ? t0 : t1); f += kWavesPerBlock) {
+                const bool has = (mybm >> f) & 1u;
+                if (!__any(has)) continue;
+                const uint32_t s = has ? slot_of((uint32_t)f, lt_lane) : 0u;
+                T g[COUT];
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) g[c] = has ? G[(size_t)s * COUT + c] : (T)0;
+                const T *wf = wt + (size_t)f * CIN * COUT;
+#pragma unroll
+                for (int k = 0; k < CIN; ++k)
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) dx[k] = fma_t(g[c], wf[k * COUT + c], dx[k]);
+            }
+        }
+    };
+    T dx[CIN];
+    if (nrounds == 1) {
+        // the common case (every tile of the models' strides >= 2): nothing but phase A's own state is live across it
+        zero_G(st.ntap);
+        __syncthreads();
+        phase_A(0, st.ntap);
+        __syncthreads();
+        phase_B(0, st.ntap);
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
+        phase_C(0, st.ntap, dx);
+    } else {
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
+        for (int r = 0; r < nrounds; ++r) {
+            const int t0 = (int)rinfo[1 + r], t1 = (int)rinfo[2 + r];
+            if (r > 0) __syncthreads();   // the previous round's phases B / C are done with G
+            zero_G(t1);
+            __syncthreads();
+            phase_A(t0, t1);
+            __syncthreads();
+            phase_B(t0, t1);
+            phase_C(t0, t1, dx);
+        }
+    }
+    // ---- grad_input rows: fixed-order sum of the four waves' partial rows
+    __syncthreads();   // red aliases wt / xt: every wave is done reading them
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
+        const int k = e >> 6;   // e & 63 == lane
+        T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
+        if (orig_lane >= 0) {
+            const size_t rr = (size_t)b * N + orig_lane;
+            if (act & 2) sum += grad_input[rr * ld.dx + k];
+            if (act & 1) sum = (addend ? sum + addend[rr * ld.add + k] : sum) * selu_slope(input[rr * ld.in + k]);
+            grad_input[rr * ld.dx + k] = sum;
+        }
+    }
+}
+
+}  // namespace conv3p

@@ -1,12 +1,9 @@
 #!/bin/bash
-# developer A/B (run ON THE GPU BOX): rocprofv3 kernel summary of bench --no-prefetch for each variants/lib_*.so
+# developer (ON THE GPU BOX): isolated kernel durations for every variants/lib_*.so (bench.py --serial under rocprofv3)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for lib in $ROOT/variants/lib_*.so; do
-  echo "== $lib"
-  rm -rf $OUT/ab_trace
-  CONV3P_HIP_LIB=$lib rocprofv3 --kernel-trace --stats -d $OUT/ab_trace -o t -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --serial > $OUT/ab_trace.log 2>&1
-  python $ROOT/tools/pmc_query.py $OUT/ab_trace/t_results.db | grep "${AB_GREP:-kernel}" | head -8
+  rm -rf /tmp/tr
+  CONV3P_HIP_LIB=$lib rocprofv3 --kernel-trace --stats -d /tmp/tr -o t -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu --no-extra --serial > /tmp/tr.log 2>&1
+  echo "== $(basename $lib)"; python $ROOT/tools/pmc_query.py /tmp/tr/t_results.db | grep "${1:-backward}"
 done
-rm -rf $OUT/ab_trace
