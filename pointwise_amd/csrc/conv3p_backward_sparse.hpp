@@ -38,7 +38,7 @@ struct __attribute__((aligned(16))) TapInfo {
 // tapmap | tapinfo[32] | rounds | qorig | slot -> centre map u8[64 * 32] | rinv | { wt | xt | soa } (red aliases {})
 template <typename T> __host__ __device__ inline size_t sparse_fixed_lds(int maxfull, int ntap, int cin, int cout)
 {
-    const size_t tail0 = (((size_t)ntap * cin * cout * sizeof(T) + 15) & ~(size_t)15) + (((size_t)64 * cin * sizeof(T) + 15) & ~(size_t)15) +
+    const size_t tail0 = (((size_t)ntap * (((size_t)cin * cout + 3) & ~(size_t)3) * sizeof(T) + 15) & ~(size_t)15) + (((size_t)64 * cin * sizeof(T) + 15) & ~(size_t)15) +
                          (size_t)kWavesPerBlock * 192 * 4;
     const size_t red = ((size_t)kWavesPerBlock * cin * 64 * sizeof(T) + 15) & ~(size_t)15;
     return (((size_t)3 * maxfull * 2 + 15) & ~(size_t)15) + 32 * sizeof(TapInfo) + 64 * 4 + 256 + 2048 +
@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     off += align16(256 * sizeof(T));
     const size_t nw = (size_t)st.ntap * CIN * COUT;
     T *red = reinterpret_cast<T *>(smem + off);                   // [4][CIN][64]: ALIASES wt | xt | soa (used after them)
-    T *wt = reinterpret_cast<T *>(smem + off);                    // W[f][k][c] as stored by the caller
-    size_t off2 = off + align16(nw * sizeof(T));
+    constexpr int WSTR = (CIN * COUT + 3) & ~3;                   // a tap's [Cin][Cout] block, 16-byte aligned: phase C reads it
+    T *wt = reinterpret_cast<T *>(smem + off);                    //   four values per LDS instruction (wave-uniform address)
+    size_t off2 = off + align16((size_t)st.ntap * WSTR * sizeof(T));
     T *xt = reinterpret_cast<T *>(smem + off2);                   // X tile [64][CIN]
     off2 += align16((size_t)64 * CIN * sizeof(T));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -89,7 +90,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
         for (int u = 0; u < 8; ++u) v[u] = filter[e0 + u * 256 < (uint32_t)nw ? e0 + u * 256 : 0u];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (e0 + u * 256 < (uint32_t)nw) wt[e0 + u * 256] = v[u];
+            if (e0 + u * 256 < (uint32_t)nw) {
+                const uint32_t e = e0 + u * 256, f = e / (CIN * COUT);
+                wt[f * WSTR + (e - f * (CIN * COUT))] = v[u];
+            }
     }
     rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
 
@@ -360,11 +364,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
                 T g[COUT];
 #pragma unroll
                 for (int c = 0; c < COUT; ++c) g[c] = has ? G[(size_t)s * COUT + c] : (T)0;
-                const T *wf = wt + (size_t)f * CIN * COUT;
+                // W[f'][k][c] in ascending address order, four per read (fp32: ds_read_b128 of a wave-uniform address)
+                typedef T wvec __attribute__((ext_vector_type(4)));
+                const wvec *w4 = reinterpret_cast<const wvec *>(wt + (size_t)f * WSTR);
 #pragma unroll
-                for (int k = 0; k < CIN; ++k)
+                for (int e4 = 0; e4 < WSTR / 4; ++e4) {
+                    const wvec w = w4[e4];
 #pragma unroll
-                    for (int c = 0; c < COUT; ++c) dx[k] = fma_t(g[c], wf[k * COUT + c], dx[k]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e4 * 4 + u;
+                        if (e < CIN * COUT) dx[e / COUT] = fma_t(g[e % COUT], w[u], dx[e / COUT]);
+                    }
+                }
             }
         }
     };
