@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
                 if (has) sj[gbase + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = (uint8_t)lane;
             }
             base += n;
-            gbase += n;
+            gbase += (n + 3u) & ~3u;   // (a tap's entries start 4-byte aligned: phase B reads four centres per LDS load)
         }
         if (threadIdx.x == 0) {
             rinfo[0] = nrounds;
@@ -302,20 +302,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
                 const TapInfo ti = tapinfo[f];
                 const int n = __popc(ti.mask_lo) + __popc(ti.mask_hi);
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int s0 = 0; s0 < n; s0 += 16) {   // four steps (16 slots) per iteration: loads first, then the products
-                    int cj[4];
+                for (int s0 = 0; s0 < n; s0 += 16) {   // 16 slots per iteration: lane group l4 takes slots s0 + 4 l4 .. + 3
+                    const int sb = s0 + 4 * l4;
+                    const uint32_t cj4 = *reinterpret_cast<const uint32_t *>(sj + ti.gbase + (sb < n ? sb : 0));   // four centres
+                    float av[4], bv[4];
                     bool ok[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int sl = s0 + 4 * u + l4;
-                        ok[u] = sl < n;
-                        cj[u] = sj[ti.gbase + (ok[u] ? sl : 0)];
-                    }
-                    float av[4], bv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int sl = ti.base + (ok[u] ? s0 + 4 * u + l4 : 0);
-                        av[u] = xtf[cj[u] * CIN + (l15 < CIN ? l15 : 0)];
+                        ok[u] = sb + u < n;
+                        const int sl = ti.base + (ok[u] ? sb + u : 0);
+                        av[u] = xtf[((cj4 >> (8 * u)) & 0xFFu) * CIN + (l15 < CIN ? l15 : 0)];
                         bv[u] = Gf[(size_t)sl * COUT + (l15 < COUT ? l15 : 0)];
                     }
 #pragma unroll
