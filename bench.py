@@ -294,6 +294,7 @@ def cfg4_report(lib, dev, steps=20, warmup=5):
     Ps = [torch.from_numpy(synth.room_like(B, N, 40 + i)).to(dev) for i in range(3)]
     Xs = [torch.from_numpy(synth.features(B, N, cin, 50 + i, points=p.cpu().numpy())).to(dev) for i, p in enumerate(Ps)]
     st = stack.Conv3pStack(cin, ncls, device=dev, seed=3)
+    st.tune(Ps[0])
     ups = [torch.from_numpy(synth.upstream_grad(B, N, ncls, 60)).to(dev)]
     ctr = [0]
 
@@ -455,6 +456,7 @@ def main():
     # whatever --warmup is
     distributed.allreduce_weight_grads(torch.zeros_like(st.fused_grad))
     distributed.barrier()
+    st.tune(tPs[0])                 # set-up: short pair lists on these clouds? -> CONV3P_CACHE_SPARSE_NEIGHBOURHOODS
     st.prepare(B_PER_GPU, N_POINTS)
     _p = tPs[0][:1, :64].contiguous()
     op.conv3p(_p, _p, st.filters[0], (1, 1, 1), stack.VOXEL)
@@ -513,6 +515,7 @@ def main():
     if extra and prefetch:
         # the same steps with no side stream at all: kernels run alone, one after the other
         st_iso = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=False)
+        st_iso.sparse_neighbourhoods = st.sparse_neighbourhoods
         st_iso.prepare(B_PER_GPU, N_POINTS)
         step_iso = make_step(st_iso, False)
         for _ in range(3):
@@ -580,7 +583,8 @@ def main():
                                          "current backward" if prefetch else "")
                                       + (", fused RCCL all-reduce of 7290 weight grads" if world > 1 else ""),
                           "global_batch": B_PER_GPU * world, "points_per_cloud": N_POINTS,
-                          "parallelism": "dp%d" % world},
+                          "parallelism": "dp%d" % world,
+                          "sparse_neighbourhoods_hint": bool(st.sparse_neighbourhoods)},
                "roofline": roofline}
         if world > 1:
             out["rccl_world"] = rccl_world

@@ -51,9 +51,12 @@ class NeighborCache:
     One cache serves one (B, N, dtype) on one device.  It is zero-filled at creation; validity afterwards
     is decided on the device by content hash, so reusing it with different clouds is always safe."""
 
-    def __init__(self, B, N, dtype, device, slots=5, max_taps=27, pairs_per_point=0, max_cin=36, max_cout=41):
+    def __init__(self, B, N, dtype, device, slots=5, max_taps=27, pairs_per_point=0, max_cin=36, max_cout=41,
+                 sparse_neighbourhoods=False):
         lib = _lib.load()
         self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout, 0)
+        # CONV3P_CACHE_SPARSE_NEIGHBOURHOODS (include/conv3p.h): tuning hint for clouds with short pair lists
+        self.sparse_neighbourhoods = bool(sparse_neighbourhoods)
         self.key = (int(B), int(N), dtype, torch.device(device))
         esz = _SFX[dtype][2]
         self.nbytes = lib.conv3p_cache_bytes(esz, B, N, ctypes.byref(self.cfg))
@@ -64,7 +67,8 @@ class NeighborCache:
     def cfg_ptr(self, points_unchanged):
         """Address of the config struct for one call; points_unchanged = the caller's promise that `points`
         holds the same bytes as at the previous cached call (CONV3P_CACHE_POINTS_UNCHANGED)."""
-        self.cfg.flags = _lib.CACHE_POINTS_UNCHANGED if points_unchanged else 0
+        self.cfg.flags = (_lib.CACHE_POINTS_UNCHANGED if points_unchanged else 0) | \
+                         (_lib.CACHE_SPARSE_NEIGHBOURHOODS if self.sparse_neighbourhoods else 0)
         return ctypes.addressof(self.cfg)
 
     def fits(self, B, N, dtype, device, ntap, cin, cout):

@@ -318,6 +318,7 @@ template <typename T> struct Call {
     // conv3p_layer_*: SELU fused into the op (pointcnn2_acsd.py:48-49).  forward: output = selu(conv);
     // backward: grad_input = (dX + addend) * selu'(input)
     bool act = false;
+    bool sparse_hint = false;      // CONV3P_CACHE_SPARSE_NEIGHBOURHOODS: short pair lists expected (see conv3p.h)
     bool accum = false;            // backward: add to the grad_input already there (column-split passes)
     const T *addend = nullptr;
     RowLd ld{0, 0, 0, 0, 0};       // row strides of the feature tensors; filled with the dense values by set_ld()
@@ -457,6 +458,7 @@ template <typename T> int sparse_cap(const Stencil<T> &st, int cin, int cout, si
         if (bud <= fixed) continue;
         long long cap = (long long)((bud - fixed) / ((size_t)cout * sizeof(T)));
         if (cap > 64LL * st.ntap) cap = 64LL * st.ntap;
+        if (cap < (long long)sparse_min_rows<T>(cin, cout)) continue;
         if (cap >= 256 || cap == 64LL * st.ntap) {
             lds = fixed + (size_t)cap * cout * sizeof(T);
             return (int)cap;
@@ -476,7 +478,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
 #ifndef CONV3P_DEV_DENSE_BACKWARD   // developer A/B build: always the dense-G kernel
     if constexpr (CI > 0 && CI < 16) {
         size_t slds = 0;
-        const int cap = only_flagged == nullptr ? sparse_cap<T>(st, CI, CO, slds) : 0;
+        const int cap = only_flagged == nullptr && c.sparse_hint ? sparse_cap<T>(st, CI, CO, slds) : 0;
         if (cap > 0) {
             const BlockMap bm = make_blockmap(d);
             Scope sc(K_BACKWARD, c.s);
@@ -733,6 +735,7 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     c.d = d;
     c.st = make_stencil<T>(d, stride, voxel);
     c.s = s;
+    c.sparse_hint = wh.persistent && (wh.flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS) != 0;
     const int ntap_max = wh.persistent ? wh.ntap_max : d.ntap;
     if (d.ntap > ntap_max) return CONV3P_ERR_WORKSPACE;
     if (wh.persistent && scratch > wh.scratch_cap) return CONV3P_ERR_WORKSPACE;
@@ -1187,7 +1190,7 @@ int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B,
     } else
     for (int l = 0; l < nl; ++l) {
         conv3p_cache_config c2 = *cfg;
-        c2.flags = l > 0 ? CONV3P_CACHE_POINTS_UNCHANGED : 0;
+        c2.flags = (l > 0 ? CONV3P_CACHE_POINTS_UNCHANGED : 0) | (cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS);
         const Where wh = persistent((int)sizeof(T), B, N, cache, cache_bytes, c2.slots, c2.max_taps, c2.pairs_per_point,
                                     c2.max_Cin, c2.max_Cout, c2.flags);
         TRY(prepare_impl<T>(points, sd->strides[l], voxel, B, N, sd->fz, sd->fy, sd->fx, wh, s));
@@ -1249,7 +1252,8 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
     for (int l = 0; l < nl; ++l) {
         if (events && !prefetched && hipStreamWaitEvent(main, ev[l], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
         conv3p_cache_config c2 = *cfg;
-        c2.flags = (l > 0 || events) ? CONV3P_CACHE_POINTS_UNCHANGED : 0;   // the first call of a step re-validates
+        c2.flags = ((l > 0 || events) ? CONV3P_CACHE_POINTS_UNCHANGED : 0) |   // the first call of a step re-validates
+                   (cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS);
         const bool head = l == sd->n_hidden;
         const int Cin = head ? CW : (l == 0 ? sd->in_channels : sd->hidden);
         const int Cout = head ? sd->num_class : sd->hidden;
@@ -1334,7 +1338,8 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
     };
     auto where = [&]() {
         return persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
-                          cfg->max_Cin, cfg->max_Cout, CONV3P_CACHE_POINTS_UNCHANGED);
+                          cfg->max_Cin, cfg->max_Cout,
+                          CONV3P_CACHE_POINTS_UNCHANGED | (cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS));
     };
     // external gradient of the concat's column blocks: the caller's, the head's, or their sum
     const T *ext = grad_concat;

@@ -35,14 +35,16 @@ struct __attribute__((aligned(16))) TapInfo {
 };
 
 // LDS of the sparse kernel apart from G [cap][Cout]:
-// tapmap | tapinfo[32] | rounds | qorig | slot -> centre map u8[64 * 32] | rinv | { wt | xt | soa } (red aliases {})
+// tapmap | tapinfo[32] | rounds | qorig | slot -> centre map u8[64 * 32] | rinv | xt | soa     (red aliases G)
 template <typename T> __host__ __device__ inline size_t sparse_fixed_lds(int maxfull, int ntap, int cin, int cout)
 {
-    const size_t tail0 = (((size_t)ntap * (((size_t)cin * cout + 3) & ~(size_t)3) * sizeof(T) + 15) & ~(size_t)15) + (((size_t)64 * cin * sizeof(T) + 15) & ~(size_t)15) +
-                         (size_t)kWavesPerBlock * 192 * 4;
-    const size_t red = ((size_t)kWavesPerBlock * cin * 64 * sizeof(T) + 15) & ~(size_t)15;
     return (((size_t)3 * maxfull * 2 + 15) & ~(size_t)15) + 32 * sizeof(TapInfo) + 64 * 4 + 256 + 2048 +
-           ((256 * sizeof(T) + 15) & ~(size_t)15) + (tail0 > red ? tail0 : red);
+           ((256 * sizeof(T) + 15) & ~(size_t)15) + (((size_t)64 * cin * sizeof(T) + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * 192 * 4;
+}
+// G must also hold the final cross-wave sum [4][Cin][64]
+template <typename T> __host__ __device__ inline size_t sparse_min_rows(int cin, int cout)
+{
+    return ((size_t)kWavesPerBlock * cin * 64 + cout - 1) / cout;
 }
 
 template <typename T, int CIN, int COUT>
@@ -68,33 +70,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     T *rinv = reinterpret_cast<T *>(smem + off);                  // rinv[n] = 1 / (T)n for n < 256
     off += align16(256 * sizeof(T));
     const size_t nw = (size_t)st.ntap * CIN * COUT;
-    T *red = reinterpret_cast<T *>(smem + off);                   // [4][CIN][64]: ALIASES wt | xt | soa (used after them)
-    constexpr int WSTR = (CIN * COUT + 3) & ~3;                   // a tap's [Cin][Cout] block, 16-byte aligned: phase C reads it
-    T *wt = reinterpret_cast<T *>(smem + off);                    //   four values per LDS instruction (wave-uniform address)
-    size_t off2 = off + align16((size_t)st.ntap * WSTR * sizeof(T));
-    T *xt = reinterpret_cast<T *>(smem + off2);                   // X tile [64][CIN]
-    off2 += align16((size_t)64 * CIN * sizeof(T));
+    T *xt = reinterpret_cast<T *>(smem + off);                    // X tile [64][CIN]
+    off += align16((size_t)64 * CIN * sizeof(T));
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *soa = reinterpret_cast<float *>(smem + off2) + wave * 192;
-    off2 += align16((size_t)kWavesPerBlock * 192 * 4);
-    const size_t redb = align16((size_t)kWavesPerBlock * CIN * 64 * sizeof(T));
-    off += off2 - off > redb ? off2 - off : redb;
+    float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
+    off += align16((size_t)kWavesPerBlock * 192 * 4);
     T *G = reinterpret_cast<T *>(smem + off);                     // [cap][COUT]
+    T *red = G;                                                   // [4][CIN][64]: ALIASES G (used after the last round)
     const int cq = wave * 16 + (lane & 15), sub = lane >> 4;
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    // filter -> LDS as it is (phase B needs no transposed copy; phase C reads W[f][k][c] with a wave-uniform f)
-    for (uint32_t e0 = threadIdx.x; e0 < (uint32_t)nw; e0 += 8 * 256) {
-        T v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = filter[e0 + u * 256 < (uint32_t)nw ? e0 + u * 256 : 0u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (e0 + u * 256 < (uint32_t)nw) {
-                const uint32_t e = e0 + u * 256, f = e / (CIN * COUT);
-                wt[f * WSTR + (e - f * (CIN * COUT))] = v[u];
-            }
-    }
     rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
 
     int b, qt;
@@ -360,18 +345,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
                 T g[COUT];
 #pragma unroll
                 for (int c = 0; c < COUT; ++c) g[c] = has ? G[(size_t)s * COUT + c] : (T)0;
-                // W[f'][k][c] in ascending address order, four per read (fp32: ds_read_b128 of a wave-uniform address)
-                typedef T wvec __attribute__((ext_vector_type(4)));
-                const wvec *w4 = reinterpret_cast<const wvec *>(wt + (size_t)f * WSTR);
+                // W[f'][k][c] straight from the caller's filter: f' is wave-uniform, so these are scalar loads (the filter,
+                // 8.7 KB for 9 -> 9, stays in the scalar cache) and the products take the weight as a scalar operand --
+                // no copy of the filter in LDS, whose 8.7 KB hold 240 more rows of G
+                const T *wf = filter + (size_t)f * CIN * COUT;
 #pragma unroll
-                for (int e4 = 0; e4 < WSTR / 4; ++e4) {
-                    const wvec w = w4[e4];
+                for (int k = 0; k < CIN; ++k)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = e4 * 4 + u;
-                        if (e < CIN * COUT) dx[e / COUT] = fma_t(g[e % COUT], w[u], dx[e / COUT]);
-                    }
-                }
+                    for (int c = 0; c < COUT; ++c) dx[k] = fma_t(g[c], wf[k * COUT + c], dx[k]);
             }
         }
     };
@@ -401,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
         }
     }
     // ---- grad_input rows: fixed-order sum of the four waves' partial rows
-    __syncthreads();   // red aliases wt / xt: every wave is done reading them
+    __syncthreads();   // red aliases G: every wave is done with its last phase C
 #pragma unroll
     for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
     __syncthreads();

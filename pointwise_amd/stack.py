@@ -37,6 +37,8 @@ class Conv3pStack:
         buffer.  Needs use_cache and fuse_selu; shapes outside the register-resident list fall back to the op-by-op
         composition below (same results)."""
         self.use_cache = use_cache
+        # CONV3P_CACHE_SPARSE_NEIGHBOURHOODS for the stack's caches: set by tune() (or by hand before the first batch)
+        self.sparse_neighbourhoods = False
         self.c_stack = c_stack and use_cache and fuse_selu
         self._inflight = None          # cache index of the batch between forward() and backward()
         self._pending = {}             # cache index -> points tensor whose geometry was prefetched into it
@@ -228,9 +230,25 @@ class Conv3pStack:
                 self._join_side(points.device)
                 self._pending.pop(idx, None)
             c = op.NeighborCache(B, N, points.dtype, points.device, slots=len(self.layers), max_taps=27,
-                                 max_cin=cmax, max_cout=cmax)
+                                 max_cin=cmax, max_cout=cmax, sparse_neighbourhoods=self.sparse_neighbourhoods)
             self._caches[idx] = c
         return c
+
+    def tune(self, points, threshold=24.0):
+        """Set-up, once per dataset (it synchronises): measure the mean neighbour count of the dilated layers on a
+        sample batch and, when the pair lists are short, give the stack's caches the CONV3P_CACHE_SPARSE_NEIGHBOURHOODS
+        hint of include/conv3p.h (ModelNet40-shaped clouds: 7-11 neighbours -> on; S3DIS-like rooms: ~50 -> off).
+        The hint only selects kernels: results stay within the op's tolerance either way."""
+        strides = sorted({s for _, _, s in self.layers if s > 1})
+        if not strides or not self.use_cache:
+            return False
+        sample = points[: min(points.shape[0], 4)].contiguous()
+        mean = max(float(op.neighbor_count(sample, (3, 3, 3), (s, s, s), VOXEL).sum(dim=2).float().mean()) for s in strides)
+        self.sparse_neighbourhoods = mean <= threshold
+        for c in self._caches:
+            if c is not None:
+                c.sparse_neighbourhoods = self.sparse_neighbourhoods
+        return self.sparse_neighbourhoods
 
     def prepare(self, B, N):
         """Set-up outside any timed region: allocate both neighbour caches for (B, N) clouds."""
@@ -240,7 +258,8 @@ class Conv3pStack:
                 c = self._caches[idx]
                 if c is None or not c.fits(B, N, self.dtype, self.device, 27, cmax, cmax):
                     self._caches[idx] = op.NeighborCache(B, N, self.dtype, self.device, slots=len(self.layers),
-                                                         max_taps=27, max_cin=cmax, max_cout=cmax)
+                                                         max_taps=27, max_cin=cmax, max_cout=cmax,
+                                                         sparse_neighbourhoods=self.sparse_neighbourhoods)
 
     def _cache_for(self, points):
         if not self.use_cache:

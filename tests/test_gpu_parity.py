@@ -777,3 +777,61 @@ def test_fp64_register_path_matches_oracle(dev, ci, co, kind, N):
     again = run_hip(dev, P, X, W, dY, s)
     for a, b in zip(got, again):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ CONV3P_CACHE_SPARSE_NEIGHBOURHOODS (populated-rows backward)
+@pytest.mark.parametrize("kind,B,N,ci,co,s,ppp", [
+    ("modelnet", 3, 700, 9, 9, (2, 2, 2), 0), ("modelnet", 2, 2048, 9, 9, (4, 4, 4), 0), ("modelnet", 2, 600, 3, 9, (3, 3, 3), 0),
+    ("modelnet", 2, 500, 12, 9, (2, 2, 2), 0), ("modelnet", 2, 500, 9, 3, (2, 2, 2), 0), ("modelnet", 2, 333, 6, 9, (1, 2, 3), 0),
+    ("room", 2, 1024, 9, 9, (2, 2, 2), 0),            # dense neighbourhoods: tiles take several rounds of taps
+    ("lattice", 2, 512, 9, 9, (2, 2, 2), 0),          # every pair on a tap boundary: forward and backward pair sets differ
+    ("identical", 1, 300, 9, 9, (2, 2, 2), 0),        # one tap, 64 rows per tile
+    ("modelnet", 2, 640, 9, 9, (2, 2, 2), 1),         # pair buffer too small: tiles search themselves inside the kernel
+    ("modelnet", 1, 70, 9, 9, (3, 3, 3), 0)])         # a ragged last tile
+def test_sparse_neighbourhoods_hint_matches_oracle(dev, kind, B, N, ci, co, s, ppp):
+    """The backward kernel the hint selects (conv3p_backward_sparse.hpp) against the oracle, through the cached op
+    entry points, plus bitwise reproducibility and the layer form with the fused SELU-gradient epilogue."""
+    P, X, W, dY = make_case(kind, B, N, ci, co, seed=1800 + N + ci)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tp, tx, tw, tdy = t(P), t(X), t(W), t(dY)
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=2, max_taps=27, pairs_per_point=ppp, max_cin=ci, max_cout=co,
+                             sparse_neighbourhoods=True)
+    y = op.conv3p(tp, tx, tw, s, VOX, cache=cache)
+    dx, dw = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=cache)
+    dx2, dw2 = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=cache, points_unchanged=True)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2)
+    dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, VOX)
+    dw_floor = 0.0
+    if kind == "identical":
+        d64 = oracle.backward(dY.astype(np.float64), P.astype(np.float64), X.astype(np.float64), W.astype(np.float64), s, VOX)[1]
+        dw_floor = rel_err(dw_ref, d64)
+    assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, s, VOX)) <= 1e-5
+    assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5
+    assert rel_err(dw.cpu().numpy(), dw_ref) <= max(2e-5, 4.0 * dw_floor)
+    # the hint changes kernels, not results beyond the op's tolerance: against the un-hinted cache
+    plain = op.NeighborCache(B, N, torch.float32, dev, slots=2, max_taps=27, pairs_per_point=ppp, max_cin=ci, max_cout=co)
+    dx0, dw0 = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=plain)
+    assert rel_err(dx.cpu().numpy(), dx0.cpu().numpy()) <= 1e-5 and rel_err(dw.cpu().numpy(), dw0.cpu().numpy()) <= 2e-5
+    if ci == 9 and co == 9:
+        add = torch.randn_like(tx)
+        act_in = op.selu(tx)                              # a SELU output as the layer's input
+        g1, w1 = op.conv3p_layer_grad(tdy, tp, act_in, tw, s, VOX, cache, grad_addend=add, points_unchanged=True)
+        g0, w0 = op.conv3p_layer_grad(tdy, tp, act_in, tw, s, VOX, plain, grad_addend=add, points_unchanged=True)
+        assert rel_err(g1.cpu().numpy(), g0.cpu().numpy()) <= 1e-5 and rel_err(w1.cpu().numpy(), w0.cpu().numpy()) <= 2e-5
+
+
+def test_stack_tune_sets_the_hint_by_measured_density(dev):
+    """Conv3pStack.tune(): ModelNet-shaped clouds (7-11 neighbours at strides 2-4) get the hint, room blocks (~50) do
+    not; the tuned classification stack matches the oracle stack."""
+    P = synth.modelnet_like(3, 1024, seed=1900)
+    st = stack.Conv3pStack(3, None, device=dev, seed=77)
+    assert st.tune(torch.from_numpy(P).to(dev)) is True
+    acts = st.forward(torch.from_numpy(P).to(dev), torch.from_numpy(P).to(dev))
+    ups = [synth.upstream_grad(3, 1024, stack.HIDDEN, 1910 + li) for li in range(4)]
+    dx, fused = st.backward([torch.from_numpy(u).to(dev) for u in ups])
+    ref_acts, ref_dx, ref_fused = _oracle_stack(P, P.copy(), [f.cpu().numpy() for f in st.filters], st.layers, ups, None)
+    for a, r in zip(acts, ref_acts):
+        assert rel_err(a.cpu().numpy(), r) <= 1e-5
+    assert rel_err(dx.cpu().numpy(), ref_dx) <= 2e-5 and rel_err(fused.cpu().numpy(), ref_fused) <= 2e-5
+    rooms = stack.Conv3pStack(9, 13, device=dev, seed=78)
+    assert rooms.tune(torch.from_numpy(synth.room_like(2, 4096, 1901)).to(dev)) is False
