@@ -548,6 +548,7 @@ struct DeepScratch {   // carved from the per-call scratch region
     uint8_t *tile_flag;    // [tiles]
     unsigned long long *pop_mask;   // [tiles] bit f: the tile has records of backward tap f (deep_order -> deep_plan)
     uint4 *tap_split;      // [tiles][F] quarter points of every (tile, tap) run (deep_order -> deep_gemm stage 1)
+    unsigned long long *tap_cmask;   // [tiles][F] centres with records of the backward tap: the rows of G_f' that exist
     uint32_t *sched;       // [8][sched_cap] launch order of the tiles per XCD (deep_sched_kernel)
     int sched_cap;
     uint32_t *tap_total;   // [64] pairs per backward tap, then [1] number of work items  (deep_plan_kernel)
@@ -572,6 +573,7 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
     s.pop_mask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * 8));
     s.tap_split = reinterpret_cast<uint4 *>(take((size_t)d.B * d.ntiles * d.ntap * 16));
+    s.tap_cmask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * d.ntap * 8));
     s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
     s.sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
     s.tap_total = reinterpret_cast<uint32_t *>(take(65 * 4));
@@ -595,7 +597,7 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     if (BWD) TRY(zero_async(ds.tap_total, 65 * 4, c.s));
     hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, c.L.pts, S.count,
                        S.pairs, S.segs, d.N, d.ntiles, d.ntap, ds.tap_meta, ds.tap_off, ds.tile_flag,
-                       BWD ? ds.tap_total : nullptr, BWD ? ds.pop_mask : nullptr, ds.tap_split);
+                       BWD ? ds.tap_total : nullptr, BWD ? ds.pop_mask : nullptr, ds.tap_split, BWD ? ds.tap_cmask : nullptr);
     hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, S.segs, d.B, d.ntiles, ds.sched_cap, ds.sched);
     if (BWD)
         hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.pop_mask, d.ntap, d.B * d.ntiles, kDwItems,
@@ -617,7 +619,7 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs, S.segs, src, Bm, d.N, d.ntiles,
                            d.ntap, ds.sched, ds.sched_cap, out, ds.tap_meta, ds.tap_off, ds.tile_flag, kreal, nreal, gbuf, xin,
-                           ds.tap_split);
+                           ds.tap_split, ds.tap_cmask);
     };
     // rows shorter than 4 floats (only possible in the 32-column class) take the variant with scalar row loads
     if constexpr (KD == 32) {
@@ -676,7 +678,7 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((deep_dw_kernel<CI, CO>), dim3(kDwItems + 64, NH), dim3(256), lds, c.s, c.L.pts, ds.tap_off,
                            ds.gbuf, input, d.N, d.ntiles, d.ntap, ds.tile_flag, ds.items, ds.tap_total + 64, ds.partials,
-                           d.Cin);
+                           d.Cin, ds.tap_cmask);
     }
     TRY(hip_ok());
     // flagged tiles: generic kernel adds into the zeroed rows / into its own grad_filter-shaped buffer

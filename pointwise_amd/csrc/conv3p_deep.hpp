@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
                                                          uint8_t *__restrict__ tile_flag,
                                                          uint32_t *__restrict__ tap_total,   // [ntap] += (may be null)
                                                          unsigned long long *__restrict__ pop_mask,   // [tile] (may be null)
-                                                         uint4 *__restrict__ tap_split)   // [tile][ntap] quarter points of every run
+                                                         uint4 *__restrict__ tap_split,   // [tile][ntap] quarter points of every run
+                                                         unsigned long long *__restrict__ tap_cmask)   // [tile][ntap] centres with records of the tap (may be null)
 {
     constexpr int R = kOrderR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,6 +127,8 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
             tile_flag[tile] = 1;
             if (pop_mask != nullptr) pop_mask[tile] = 0ull;
         }
+        if (tap_cmask != nullptr)
+            for (uint32_t f = tid; f < (uint32_t)ntap; f += 256) tap_cmask[tile * (size_t)ntap + f] = 0ull;
         return;
     }
     if (tid == 0) tile_flag[tile] = 0;
@@ -223,6 +226,13 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
     // Quarter points of every tap's run, moved forward to the next change of centre (a run is centre-major, centres in
     // lane order): deep_gemm_kernel's stage 1 walks the four parts of a run with four thread groups, and a centre
     // must belong to exactly one of them.  split[f] = {a1, a2, a3, length}, positions relative to the run's start.
+    // the centres that have records of tap f: the rows of G_f' that are not zero (deep_gemm stores only those for the
+    // grad_filter kernel, which then contracts over them instead of all 64)
+    if (tap_cmask != nullptr)
+        for (uint32_t f = wave; f < (uint32_t)ntap; f += 4) {
+            const uint64_t m = __ballot(hist[f * 64u + lane] != 0u);
+            if (lane == 0) tap_cmask[tile * (size_t)ntap + f] = m;
+        }
     if (tap_split != nullptr)
         for (uint32_t f = wave; f < (uint32_t)ntap; f += 4) {
             int len;
@@ -350,7 +360,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                                                         int kreal, int nreal,   // real row lengths of src / out
                                                         float *__restrict__ gbuf,   // BWD: [tile][tap][64][KDIM] <- M_f
                                                         const float *__restrict__ xin,   // BWD: the layer's input
-                                                        const uint4 *__restrict__ tap_split)   // [tile][tap] quarter points
+                                                        const uint4 *__restrict__ tap_split,   // [tile][tap] quarter points
+                                                        const unsigned long long *__restrict__ tap_cmask)   // BWD: [tile][tap] centres with records
 {
     constexpr int LDA = KDIM + 4;                         // rows 16-byte aligned (stage 1 stores 4 columns at once)
     constexpr int TG = KDIM < 256 ? 256 / KDIM : 1;        // taps per super-step = thread groups of stage 1
@@ -574,11 +585,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
         GDBG(0)
         const int ntp = nne - t0 < TG ? nne - t0 : TG;       // taps of this super-step
         // grad_input pass: every M_f (= G_f' of this tile) also goes to gbuf, the grad_filter kernel's B operand
+        // (only the rows of the centres that have the tap -- the others are zero --, packed in centre order: row r of
+        // the stored block is the r-th set bit of tap_cmask; on the SceneNN-shaped rooms 42 % of the rows)
         if (BWD && gbuf != nullptr) {
             for (int g = 0; g < ntp; ++g) {
                 const float *Af = A + g * 64 * LDA;
-                float *gt = gbuf + (tile_id * (size_t)ntap + taps[t0 + g]) * 64 * KDIM;
-                for (int e = threadIdx.x; e < 64 * KDIM; e += 256) gt[e] = Af[(e / KDIM) * LDA + (e % KDIM)];
+                const uint32_t fg = taps[t0 + g];
+                const unsigned long long cm = tap_cmask[tile_id * (size_t)ntap + fg];
+                const int nrow = __popcll(cm);
+                float *gt = gbuf + (tile_id * (size_t)ntap + fg) * 64 * KDIM;
+                for (int e = threadIdx.x; e < nrow * (KDIM / 4); e += 256) {
+                    const int rr = e / (KDIM / 4), c4 = e % (KDIM / 4);
+                    // centre of packed row rr = position of the rr-th set bit: 6-step search on the prefix counts
+                    int pos = 0;
+#pragma unroll
+                    for (int sh = 32; sh > 0; sh >>= 1) {
+                        const int below = __popcll(cm & ((1ull << (pos + sh)) - 1ull));
+                        pos += below <= rr ? sh : 0;
+                    }
+                    const float *ar = Af + pos * LDA + 4 * c4;
+                    *reinterpret_cast<float4 *>(gt + (size_t)rr * KDIM + 4 * c4) = make_float4(ar[0], ar[1], ar[2], ar[3]);
+                }
             }
         }
         // ---- stage 2: out += M_f . Bm[f] for the super-step's taps, as ONE flat sequence of k-groups (KG MFMA
@@ -826,7 +853,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     const PointRec<float> *__restrict__ pts, const uint32_t *__restrict__ tap_off, const float *__restrict__ gbuf,
     const float *__restrict__ input, int N, int ntiles, int ntap, const uint8_t *__restrict__ tile_flag,
     const uint4 *__restrict__ items, const uint32_t *__restrict__ nitems, float *__restrict__ partials,
-    int cin)   // real input channels (<= CIN); the partial slots are [CIN][COUT]
+    int cin,   // real input channels (<= CIN); the partial slots are [CIN][COUT]
+    const unsigned long long *__restrict__ tap_cmask)   // [tile][tap] centres with records: the packed rows of gbuf
 {
     constexpr int NH = COUT >= 64 ? 2 : 1;                 // column halves (blockIdx.y)
     constexpr int CH = COUT / NH;
@@ -857,9 +885,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         const uint32_t *toff = tap_off + tile * (size_t)(ntap + 1);
         if (toff[f] == toff[f + 1] || tile_flag[tile]) continue;   // uniform: nothing with this tap / generic kernel's tile
         const int b = (int)(tile / ntiles);
+        // the tile's centres that have tap f: only their rows of G_f' were stored (packed, centre order) and only they
+        // enter the contraction; K is padded to a multiple of 8 with zero rows of G
+        const unsigned long long cm = tap_cmask[tile * (size_t)ntap + f];
+        const int nrow = __popcll(cm), npad = (nrow + 7) & ~7;
         __syncthreads();                                    // previous tile's X / G consumed
-        if (wave == 0) qorig[lane] = pts[tile * kTile + lane].idx;
-        // G tile half: [64][CH] of the stored [64][COUT] block (16-byte loads, all of a thread's in flight together)
+        if (wave == 0) {
+            const int orig = pts[tile * kTile + lane].idx;
+            if ((cm >> lane) & 1ull) qorig[__popcll(cm & ((1ull << lane) - 1ull))] = orig;   // packed row -> original index
+        }
+        // G tile half: [nrow][CH] of the stored block (16-byte loads, all of a thread's in flight together)
         {
             const float *gt = gbuf + (tile * (size_t)ntap + f) * 64 * COUT + c0;
             constexpr int GPT = (64 * (CH / 4)) / 256;       // float4 per thread
@@ -867,13 +902,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
             for (int u = 0; u < GPT; ++u) {
                 const int e = (int)threadIdx.x + 256 * u;
-                gv[u] = *reinterpret_cast<const float4 *>(gt + (size_t)(e / (CH / 4)) * COUT + 4 * (e % (CH / 4)));
+                const int rr = e / (CH / 4);
+                gv[u] = *reinterpret_cast<const float4 *>(gt + (size_t)(rr < nrow ? rr : 0) * COUT + 4 * (e % (CH / 4)));
             }
 #pragma unroll
             for (int u = 0; u < GPT; ++u) {
                 const int e = (int)threadIdx.x + 256 * u;
-                float *gr = G + (e / (CH / 4)) * LDG + 4 * (e % (CH / 4));
-                gr[0] = gv[u].x; gr[1] = gv[u].y; gr[2] = gv[u].z; gr[3] = gv[u].w;
+                const int rr = e / (CH / 4);
+                if (rr < npad) {
+                    float *gr = G + rr * LDG + 4 * (e % (CH / 4));
+                    const bool on = rr < nrow;
+                    gr[0] = on ? gv[u].x : 0.f; gr[1] = on ? gv[u].y : 0.f; gr[2] = on ? gv[u].z : 0.f; gr[3] = on ? gv[u].w : 0.f;
+                }
             }
         }
         __syncthreads();                                    // qorig visible
@@ -883,24 +923,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
             for (int u = 0; u < XPT; ++u) {
                 const int e = (int)threadIdx.x + 256 * u;
-                const int orig = qorig[e / (CIN / 4)];
+                const int rr = e / (CIN / 4);
+                const int orig = rr < nrow ? qorig[rr] : -1;
                 xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (orig >= 0) xv[u] = load_row4(input + ((size_t)b * N + orig) * cin, 4 * (e % (CIN / 4)), cin);
             }
 #pragma unroll
             for (int u = 0; u < XPT; ++u) {
                 const int e = (int)threadIdx.x + 256 * u;
-                float *xr = X + (e / (CIN / 4)) * LDX + 4 * (e % (CIN / 4));
-                xr[0] = xv[u].x; xr[1] = xv[u].y; xr[2] = xv[u].z; xr[3] = xv[u].w;
+                if (e / (CIN / 4) < npad) {
+                    float *xr = X + (e / (CIN / 4)) * LDX + 4 * (e % (CIN / 4));
+                    xr[0] = xv[u].x; xr[1] = xv[u].y; xr[2] = xv[u].z; xr[3] = xv[u].w;
+                }
             }
         }
         __syncthreads();
         if (w_on) {
-            // A[i = k][kk = centre] = X[centre][k], B[kk = centre][j = c] = G[centre][c]: 32 k-steps, 4 at a time
+            // A[i = k][kk = row] = X[row][k], B[kk = row][j = c] = G[row][c]: npad / 2 k-steps, 4 at a time
             const float *xa = X + half * LDX + wm * PM * 32 + (lane & 31);
             const float *gb = G + half * LDG + wn * PN * 32 + (lane & 31);
-#pragma unroll
-            for (int s4 = 0; s4 < 32; s4 += 4) {
+            for (int s4 = 0; s4 < npad / 2; s4 += 4) {
                 float a[4][PM], bv[4][PN];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
