@@ -521,7 +521,7 @@ int zero_async(void *p, size_t bytes, hipStream_t s)
 // Channel shapes served by the matrix-core kernels of conv3p_deep.hpp (fp32 only): every layer with up to 128
 // channels on either side, padded to the instantiated sizes {32, 64, 128}, plus the 128 -> 256 layer of BASELINE
 // config 5.  (Cin, Cout) below are the PADDED sizes.
-#define CONV3P_DEEP_SHAPES(X) X(128, 256) X(32, 32) X(32, 64) X(32, 128) X(64, 32) X(64, 64) X(64, 128) X(128, 32) X(128, 64) X(128, 128)
+#define CONV3P_DEEP_SHAPES(X) X(128, 256) X(256, 256) X(256, 128) X(32, 32) X(32, 64) X(32, 128) X(64, 32) X(64, 64) X(64, 128) X(128, 32) X(128, 64) X(128, 128)
 
 inline int deep_pad(int c) { return c <= 32 ? 32 : c <= 64 ? 64 : c <= 128 ? 128 : c <= 256 ? 256 : 0; }
 // padded (Cin, Cout) of a layer the deep path takes, or false
@@ -531,8 +531,11 @@ inline bool deep_class(int elem, int cin, int cout, int &cip, int &cop)
     cip = deep_pad(cin);
     cop = deep_pad(cout);
     if (cip == 0 || cop == 0) return false;
-    if (cop == 256) return cin == 128 && cout == 256;     // only the exact cfg5 layer at 256
-    return cip <= 128;
+    // (padded to the instantiated sizes; 129 .. 256 channels on either side: the 128 -> 256, 256 -> 256 and 256 -> 128 classes)
+#define X(ci, co) if (cip == ci && cop == co) return true;
+    CONV3P_DEEP_SHAPES(X)
+#undef X
+    return false;
 }
 inline bool deep_shape(int elem, int cin, int cout)
 {

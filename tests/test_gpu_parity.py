@@ -509,7 +509,8 @@ def test_stack_with_cache_hints_over_changing_batches(dev):
 
 
 # ------------------------------------------------------------------ deep-channel (matrix-core) path
-@pytest.mark.parametrize("ci,co", [(128, 256), (64, 128), (128, 128), (3, 64), (37, 2), (7, 43)])
+@pytest.mark.parametrize("ci,co", [(128, 256), (64, 128), (128, 128), (3, 64), (37, 2), (7, 43), (256, 256), (256, 128), (200, 130),
+                                   (129, 250)])
 def test_deep_channel_path_matches_oracle(dev, ci, co):
     """cfg5-shaped layers go through the factorised MFMA kernels (conv3p_deep.hpp); room-like data, several
     tiles per cloud, both ops.  The odd shapes exercise the padded instantiations: rows shorter than one 16-byte
@@ -525,9 +526,12 @@ def test_deep_channel_path_matches_oracle(dev, ci, co):
     check_against(ref, run_hip(dev, P, X, W, dY, s), np.float32)
 
 
-def test_deep_channel_path_is_used_and_reproducible(dev):
+@pytest.mark.parametrize("ci,co", [(128, 256), (256, 256), (256, 128), (200, 200)])
+def test_deep_channel_path_is_used_and_reproducible(dev, ci, co):
+    """128 -> 256 (cfg5) and the 256-channel classes (256 -> 256, 256 -> 128, padded 200 -> 200) run on the matrix-core
+    kernels -- not on the global-atomics kernels -- and are bitwise reproducible."""
     lib = _lib.load()
-    P, X, W, dY = make_case("room", 1, 256, 128, 256, seed=960)
+    P, X, W, dY = make_case("room", 1, 256, ci, co, seed=960)
     lib.conv3p_profile_reset()
     lib.conv3p_profile_enable(1)
     a = _both(dev, None, P, X, W, dY, (1, 1, 1))
