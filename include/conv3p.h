@@ -129,8 +129,8 @@ typedef struct conv3p_cache_config {
  * gives results for the previous clouds. */
 #define CONV3P_CACHE_POINTS_UNCHANGED 1
 /* Tuning hint, valid for the lifetime of the cache: the clouds' neighbourhoods are SPARSE -- on average at most
- * ~24 neighbours per point for the dilated stencils, e.g. surface-sampled objects at N <= 2048 (ModelNet40 clouds
- * have 7-11 at strides 2-4).  The backward of the dilated narrow layers then keeps its G matrix
+ * ~30 neighbours per point for the dilated stencils, e.g. surface-sampled objects at N <= 2048 (ModelNet40-shaped
+ * clouds have 7-27 at strides 2-4; measured crossover of the two kernels between 27 and 41).  The backward of the dilated narrow layers then keeps its G matrix
  * only for the populated (centre, tap) rows (37 KiB of LDS instead of 79: four workgroups per CU), which pays when
  * the pair lists are short (cfg2: -7 % per step) and costs when they are long (S3DIS-like rooms, ~50 neighbours:
  * +30 % on those kernels).  Results are the reference's either way (same decisions, tolerance of the op); they

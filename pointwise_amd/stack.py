@@ -234,15 +234,16 @@ class Conv3pStack:
             self._caches[idx] = c
         return c
 
-    def tune(self, points, threshold=24.0):
+    def tune(self, points, threshold=32.0):
         """Set-up, once per dataset (it synchronises): measure the mean neighbour count of the dilated layers on a
         sample batch and, when the pair lists are short, give the stack's caches the CONV3P_CACHE_SPARSE_NEIGHBOURHOODS
-        hint of include/conv3p.h (ModelNet40-shaped clouds: 7-11 neighbours -> on; S3DIS-like rooms: ~50 -> off).
+        hint of include/conv3p.h (ModelNet40-shaped clouds: 7-27 neighbours -> on; S3DIS-like rooms: 41-55 -> off; measured
+        crossover of the two backward kernels between 27 and 41 neighbours, tools/shape_time.py).
         The hint only selects kernels: results stay within the op's tolerance either way."""
         strides = sorted({s for _, _, s in self.layers if s > 1})
         if not strides or not self.use_cache:
             return False
-        sample = points[: min(points.shape[0], 4)].contiguous()
+        sample = points[: min(points.shape[0], 8)].contiguous()
         mean = max(float(op.neighbor_count(sample, (3, 3, 3), (s, s, s), VOXEL).sum(dim=2).float().mean()) for s in strides)
         self.sparse_neighbourhoods = mean <= threshold
         for c in self._caches:
