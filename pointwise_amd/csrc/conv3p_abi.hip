@@ -428,6 +428,22 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
+#ifndef CONV3P_DEV_NO_WIDE_FORWARD   // developer A/B build: the register-path kernel for every listed shape
+    if constexpr (sizeof(T) == 4 && CI >= 16 && CI <= 48 && CI % 4 == 0 && CO <= 16) {
+        // per-(centre, tap) sums, then matrix-core products with W[f] (conv3p_forward_wide.hpp)
+        if (only_flagged == nullptr && st.ntap <= 31) {
+            const size_t wlds = forward_wide_lds(st.maxfull, st.ntap);
+            const BlockMap bm = make_blockmap(d);
+            Scope sc(K_FORWARD, c.s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(forward_wide_kernel<CI, CO>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+            hipLaunchKernelGGL((forward_wide_kernel<CI, CO>), dim3(grid_of(bm)), dim3(256), wlds, c.s, c.L.pts, c.L.boxes,
+                               S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, bm, output,
+                               c.act ? 1 : 0, st.window ? c.L.cmin : nullptr, S.tcount, c.ld);
+            return hip_ok();
+        }
+    }
+#endif
     const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * ((CI * CO) | 1) * sizeof(T)) : 0) +
                        a16((size_t)st.ntap * kCntStride * sizeof(T)) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
@@ -447,14 +463,15 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
 // four (else three, else two) workgroups per CU; 0: use backward_kernel's dense G.
 template <typename T> int sparse_cap(const Stencil<T> &st, int cin, int cout, size_t &lds)
 {
-    if (st.ntap > 32 || cin >= 16 || cin < 1 || cout < 1) return 0;   // (>= 16 inputs: the dense kernel's matrix-core phases)
+    if (st.ntap > 32 || cin < 1 || cout < 1 || cout > 16) return 0;   // (phase B holds the output channels in one 16-wide block)
     // Undilated stencils populate a third of a centre's taps and more (adjacent cells: 9 of 27 on the ModelNet-shaped
     // clouds, 650-850 rows per tile): their tiles would take two rounds, each walking the pair lists again
     // (measured: 3 -> 9 stride 1 at the cfg2 size 63.8 us against 49.5 us dense).  Dilated ones: 210-450 rows.
-    if (st.step[0] * st.step[1] * st.step[2] == 1) return 0;
+    if (cin < 16 && st.step[0] * st.step[1] * st.step[2] == 1) return 0;
     const size_t fixed = sparse_fixed_lds<T>(st.maxfull, st.ntap, cin, cout) + 64;
     const size_t budgets[3] = {40960, 54608, 81920};
     for (size_t bud : budgets) {
+        if (cin >= 16 && bud < 81920) continue;   // wide rows: 2 waves per SIMD for the registers (dX rows of Cin values)
         if (bud <= fixed) continue;
         long long cap = (long long)((bud - fixed) / ((size_t)cout * sizeof(T)));
         if (cap > 64LL * st.ntap) cap = 64LL * st.ntap;
@@ -476,9 +493,12 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
 #ifndef CONV3P_DEV_DENSE_BACKWARD   // developer A/B build: always the dense-G kernel
-    if constexpr (CI > 0 && CI < 16) {
+    if constexpr (CI > 0 && CO <= 16 && sizeof(T) == 4) {
         size_t slds = 0;
-        const int cap = only_flagged == nullptr && c.sparse_hint ? sparse_cap<T>(st, CI, CO, slds) : 0;
+        // narrow layers: on the caller's hint (short pair lists); layers of >= 16 inputs: always -- their dense G
+        // plus the transposed filter take 151 KiB of LDS (one workgroup per CU), the populated rows fit two
+        const bool use = CI >= 16 || c.sparse_hint;
+        const int cap = only_flagged == nullptr && use ? sparse_cap<T>(st, CI, CO, slds) : 0;
         if (cap > 0) {
             const BlockMap bm = make_blockmap(d);
             Scope sc(K_BACKWARD, c.s);

@@ -22,6 +22,15 @@
 // backward_kernel); its slots come from the same masks (the search computes them for such tiles too).
 #pragma once
 
+#ifndef CONV3P_SP_DEPTH_NARROW
+#define CONV3P_SP_DEPTH_NARROW 3
+#endif
+#ifndef CONV3P_SP_DEPTH_WIDE
+#define CONV3P_SP_DEPTH_WIDE 4   // phase A gather depth of the >= 16-input layers (2 waves per SIMD: 256 registers)
+#endif
+#ifndef CONV3P_SP_CHSPLIT
+#define CONV3P_SP_CHSPLIT 1   // developer A/B: 0 = a centre's sub-lanes take different records (merged by lane swaps)
+#endif
 #ifndef CONV3P_SP_ABLATE
 #define CONV3P_SP_ABLATE 0   // developer ablation switch (tools/ablate_sparse.sh); 0 in every shipped build
 #endif
@@ -48,7 +57,7 @@ template <typename T> __host__ __device__ inline size_t sparse_min_rows(int cin,
 }
 
 template <typename T, int CIN, int COUT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void backward_sparse_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 4 : 2))) void backward_sparse_kernel(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const uint32_t *__restrict__ qbm, const T *__restrict__ grad_out, const T *__restrict__ input,
@@ -77,7 +86,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     off += align16((size_t)kWavesPerBlock * 192 * 4);
     T *G = reinterpret_cast<T *>(smem + off);                     // [cap][COUT]
     T *red = G;                                                   // [4][CIN][64]: ALIASES G (used after the last round)
-    const int cq = wave * 16 + (lane & 15), sub = lane >> 4;
+    // narrow layers: sub-lanes of a centre 16 lanes apart (their merge swaps 16- / 32-lane blocks); wide layers: ADJACENT
+    // lanes, so that their pieces of one dY row and their common record form one access for the texture addresser
+    constexpr bool kChSplit = CONV3P_SP_CHSPLIT && CIN >= 16;
+    const int cq = kChSplit ? wave * 16 + (lane >> 2) : wave * 16 + (lane & 15), sub = kChSplit ? (lane & 3) : (lane >> 4);
 
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
@@ -94,10 +106,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     bool overflow = false;
     for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
     const uint2 sg0 = qsegs[(tile_id * ngroups) * 64 + cq];
-    PairEntry rec0[3];
+    constexpr int kDepth = CIN < 16 ? CONV3P_SP_DEPTH_NARROW : CONV3P_SP_DEPTH_WIDE;   // records in flight per lane in phase A
+    PairEntry rec0[kDepth - 1];
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
-        const uint32_t i0 = (uint32_t)(sub + 4 * sl);
+    for (int sl = 0; sl < kDepth - 1; ++sl) {
+        const uint32_t i0 = kChSplit ? (uint32_t)sl : (uint32_t)(sub + 4 * sl);
         rec0[sl] = pairs[sg0.x + (i0 < sg0.y && sg0.y != kSegOverflow ? i0 : 0u)];
     }
     if (wave == 0) {
@@ -174,6 +187,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     auto phase_A = [&](int t0, int t1) {
         // ---- phase A
         if (CONV3P_SP_ABLATE & 1) {
+        } else if (!overflow && kChSplit) {
+            // The four sub-lanes of a centre walk its list TOGETHER and split the output channels (13: 4 + 4 + 4 + 1;
+            // 9: 3 + 3 + 3): every lane owns its G entries, so no two lanes ever meet on an address and nothing has
+            // to be merged across lanes (measured on 36 -> 13, rooms, stride 1: the lane-swap merge of the
+            // record-split walk below was 180 of phase A's 305 us -- with ~80 pairs over ~12 taps per centre its
+            // sub-lanes met on a tap in nearly every step).  Record and count loads are shared by the four lanes
+            // (one address), the dY row is read as one <= 4-element piece per lane.
+            constexpr int CPL = (COUT + 3) / 4;                       // channels per sub-lane
+            const int c0 = sub * CPL;
+            const int nc = COUT - c0 < 0 ? 0 : (COUT - c0 < CPL ? COUT - c0 : CPL);
+            constexpr int kShiftLast = 4 * CPL - COUT;                // the last piece is read from the row's end backwards
+            const int start = c0 < COUT - CPL ? c0 : COUT - CPL;
+            for (int g = 0; g < ngroups; ++g) {
+                const uint2 sg = g == 0 ? sg0 : qsegs[(tile_id * ngroups + g) * 64 + cq];
+                const PairEntry *pe = pairs + sg.x;
+                PairEntry rec[kDepth];
+                bool lv[kDepth];
+                int cn[kDepth];
+                uint32_t row[kDepth];
+                T val[kDepth][CPL];
+                auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
+                auto gather = [&](int sl, uint32_t i) {
+                    const uint32_t fb = code_bwd(rec[sl].code);
+                    lv[sl] = i < sg.y && code_fwd(rec[sl].code) != kNoTap && fb != kNoTap && (int)fb >= t0 && (int)fb < t1;
+                    row[sl] = slot_of(lv[sl] ? fb : (uint32_t)t0, lt_cq);
+                    cn[sl] = cnt_cloud[lv[sl] ? (size_t)rec[sl].cand * st.ntap + fb : (size_t)0];
+                    RowLoader<T, CPL>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy + start, val[sl]);
+                };
+#pragma unroll
+                for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = g == 0 ? rec0[sl] : ld_rec((uint32_t)sl);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, (uint32_t)sl);
+                uint32_t i = 0;
+                bool more = true;
+                while (more) {
+#pragma unroll
+                    for (int j = 0; j < kDepth; ++j) {
+                        if (!__any(i < sg.y)) {
+                            more = false;
+                            break;
+                        }
+                        rec[(j + kDepth - 1) % kDepth] = ld_rec(i + (kDepth - 1));
+                        gather((j + kDepth - 2) % kDepth, i + (kDepth - 2));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (lv[j] & (cn[j] != 0)) {                                               // .cpp:679
+                            const T rcpb = cn[j] < 256 ? rinv[cn[j]] : (T)1 / (T)cn[j];            // .cpp:692, :696
+                            T *grow = G + (size_t)row[j] * COUT + c0;
+#pragma unroll
+                            for (int c = 0; c < CPL; ++c) {
+                                const T x = (sub == 3 && c + kShiftLast < CPL) ? val[j][(c + kShiftLast) % CPL] : val[j][c];
+                                if (c < nc) grow[c] += x * rcpb;
+                            }
+                        }
+                        i += 1;
+                    }
+                }
+            }
         } else if (!overflow) {
             for (int g = 0; g < ngroups; ++g) {
                 const uint2 sg = g == 0 ? sg0 : qsegs[(tile_id * ngroups + g) * 64 + cq];
@@ -182,7 +253,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
                     const uint32_t fb = code_bwd(rc.code);
                     return i < sg.y && code_fwd(rc.code) != kNoTap && fb != kNoTap && (int)fb >= t0 && (int)fb < t1;
                 };
-                constexpr int kDepth = 3;
                 PairEntry rec[kDepth];
                 bool lv[kDepth];
                 int cn[kDepth];
@@ -192,8 +262,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
                 auto gather = [&](int sl, uint32_t i) {
                     lv[sl] = live_rec(rec[sl], i);
                     row[sl] = slot_of(lv[sl] ? code_bwd(rec[sl].code) : (uint32_t)t0, lt_cq);
-                    cn[sl] = cnt_cloud[lv[sl] ? (size_t)rec[sl].cand * st.ntap + code_bwd(rec[sl].code) : (size_t)0];
-                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy, val[sl]);
+                    cn[sl] = cnt_cloud[lv[sl] && !(CONV3P_SP_ABLATE & 32) ? (size_t)rec[sl].cand * st.ntap + code_bwd(rec[sl].code) : (size_t)0];
+                    RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] && !(CONV3P_SP_ABLATE & 32) ? rec[sl].cand : 0u) * ld.dy, val[sl]);
                 };
 #pragma unroll
                 for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = g == 0 ? rec0[sl] : ld_rec(sub + 4 * sl);
@@ -286,31 +356,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
             for (int f = t0 + ((wave - t0) & (kWavesPerBlock - 1)); f < t1; f += kWavesPerBlock) {
                 const TapInfo ti = tapinfo[f];
                 const int n = __popc(ti.mask_lo) + __popc(ti.mask_hi);
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                constexpr int NKB = (CIN + 15) / 16;   // blocks of 16 input channels (M of the product)
+                f32x4 acc0[NKB], acc1[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    acc0[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc1[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 for (int s0 = 0; s0 < n; s0 += 16) {   // 16 slots per iteration: lane group l4 takes slots s0 + 4 l4 .. + 3
                     const int sb = s0 + 4 * l4;
                     const uint32_t cj4 = *reinterpret_cast<const uint32_t *>(sj + ti.gbase + (sb < n ? sb : 0));   // four centres
-                    float av[4], bv[4];
+                    float av[4][NKB], bv[4];
                     bool ok[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         ok[u] = sb + u < n;
                         const int sl = ti.base + (ok[u] ? sb + u : 0);
-                        av[u] = xtf[((cj4 >> (8 * u)) & 0xFFu) * CIN + (l15 < CIN ? l15 : 0)];
+                        const float *xr = xtf + ((cj4 >> (8 * u)) & 0xFFu) * CIN;
+#pragma unroll
+                        for (int kb = 0; kb < NKB; ++kb) av[u][kb] = xr[kb * 16 + l15 < CIN ? kb * 16 + l15 : 0];
                         bv[u] = Gf[(size_t)sl * COUT + (l15 < COUT ? l15 : 0)];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const float a = (ok[u] && l15 < CIN) ? av[u] : 0.0f, bb = (ok[u] && l15 < COUT) ? bv[u] : 0.0f;
-                        if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc1, 0, 0, 0);
-                        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc0, 0, 0, 0);
+                        const float bb = (ok[u] && l15 < COUT) ? bv[u] : 0.0f;
+#pragma unroll
+                        for (int kb = 0; kb < NKB; ++kb) {
+                            const float a = (ok[u] && kb * 16 + l15 < CIN) ? av[u][kb] : 0.0f;
+                            if (u & 1) acc1[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc1[kb], 0, 0, 0);
+                            else acc0[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc0[kb], 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int k = 4 * l4 + rr;
-                    if (k < CIN && l15 < COUT) so[((size_t)f * CIN + k) * COUT + l15] = acc0[rr] + acc1[rr];
-                }
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int k = kb * 16 + 4 * l4 + rr;
+                        if (k < CIN && l15 < COUT) so[((size_t)f * CIN + k) * COUT + l15] = acc0[kb][rr] + acc1[kb][rr];
+                    }
             }
         } else {
             for (int row = t0 * COUT + (int)threadIdx.x; row < t1 * COUT; row += blockDim.x) {

@@ -98,6 +98,10 @@ __device__ __forceinline__ float fma_t(float a, float b, float c) { return __bui
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 
+// LDS accumulate without a returned value: ds_add_f32 / ds_add_f64 (fire and forget, no lgkmcnt wait for a result).
+__device__ __forceinline__ void lds_add(float *p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_add(double *p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // Gather of a feature row with dword alignment only: rows are C*sizeof(T) bytes apart, so the compiler
 // cannot prove 16-B alignment and would emit C scalar loads, each of which costs the texture-addresser a
 // full pass over 64 scattered cache lines.  global_load_dwordx4 only needs dword alignment on gfx950:

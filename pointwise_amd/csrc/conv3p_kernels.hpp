@@ -1540,3 +1540,4 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T *src, T *dst, si
 }  // namespace conv3p
 
 #include "conv3p_backward_sparse.hpp"
+#include "conv3p_forward_wide.hpp"

@@ -16,7 +16,7 @@ for name, cname, n, avg in db.execute(
         continue
     key = name.split("(")[0].replace("void conv3p::", "").split("<")[0]
     key = {"search_multi_kernel": "search_kernel", "prep_sort_kernel": "prep_kernel",
-           "reduce_multi_kernel": "reduce_partials_kernel"}.get(key, key)
+           "reduce_multi_kernel": "reduce_partials_kernel", "backward_sparse_kernel": "backward_kernel"}.get(key, key)
     a = acc.setdefault(key, {}).setdefault(cname, [0.0, 0])
     a[0] += avg * n
     a[1] += n
