@@ -174,6 +174,7 @@ template <typename T> struct Layout {
         int32_t *count, *tcount;   // populations: original-index order (B,N,F) / tile-major [tile][F][64]
         uint2 *segs, *qsegs;
         uint32_t *qbm;             // [B][ntiles][64] backward taps each centre's list holds (bit f'; <= 32 taps)
+        uint32_t *sched;           // [8][ceil(B / 8) * ntiles] launch order of the tiles per XCD (tile_sched_kernel)
         PairEntry *pairs;
     };
     std::vector<Slot> slot;
@@ -228,6 +229,7 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
         S.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups));
         S.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups * 64));
         S.qbm = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * ntiles * 64));
+        S.sched = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * 8 * (size_t)((B + 7) / 8) * ntiles));
         S.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * (size_t)B * ppc));
     }
     L.partials = reinterpret_cast<T *>(take(scratch_bytes));
@@ -283,8 +285,20 @@ size_t backward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPe
     return deep > plain ? deep : plain;
 }
 
+// Shapes whose forward runs as transform + gather (conv3p_forward_taps.hpp): fp32 register-path shapes with at least
+// 16 inputs and at most 16 outputs.  Their scratch: Z [B N][ntap][16] floats.
+inline bool tap_forward_shape(int elem, int cin, int cout)
+{
+#ifdef CONV3P_DEV_NO_TAP_FORWARD   // developer A/B build
+    return false;
+#endif
+    return elem == 4 && small_shape(elem, cin, cout) && cin >= 16 && cin % 4 == 0 && cout <= 16;
+}
+inline size_t tap_forward_bytes(const Dims &d) { return (size_t)d.B * d.N * (size_t)d.ntap * kZRow * 4; }
+
 size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
 {
+    if (tap_forward_shape(elem, d.Cin, d.Cout)) return tap_forward_bytes(d);
     if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
         return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     return 0;
@@ -312,6 +326,7 @@ template <typename T> struct Call {
     CacheCtl cc;
     hipStream_t s;
     bool deep_scratch_ok = false;  // the scratch region can hold the deep path's side arrays
+    bool tap_scratch_ok = false;   // ... the transform + gather forward's Z array
     bool evicted_hinted = false;   // slot re-assigned to a new stencil while prep is skipped: reset its allocators
     bool skip_prep = false;     // caller promised unchanged points
     bool skip_search = false;   // ... and this slot's lists were already enqueued for them
@@ -399,6 +414,16 @@ template <typename T> int run_cloud_min(const T *points, const Call<T> &c)
 }
 
 // search.  count: where the populations go.
+// launch order of a slot's tiles for the list-walking kernels
+template <typename SlotT> inline const uint32_t *sched_of(const SlotT &S)
+{
+#ifdef CONV3P_DEV_NO_SCHED   // developer A/B build: BlockMap order
+    return nullptr;
+#else
+    return S.sched;
+#endif
+}
+
 template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
     if (c.skip_search && with_pairs) return CONV3P_OK;
@@ -418,6 +443,11 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
         };
         if (st.window) launch(search_kernel<T, true>, c.L.cmin);
         else launch(search_kernel<T, false>, static_cast<const T *>(nullptr));
+        if (with_pairs) {
+            SchedJobs sj;
+            sj.job[0] = SchedJob{S.segs, S.sched};
+            hipLaunchKernelGGL(tile_sched_kernel, dim3(8, 1), dim3(1024), 0, c.s, sj, d.B, d.ntiles, c.L.ngroups, bm.rounds * d.ntiles);
+        }
     }
     return hip_ok();
 }
@@ -428,22 +458,25 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
-#ifndef CONV3P_DEV_NO_WIDE_FORWARD   // developer A/B build: the register-path kernel for every listed shape
-    if constexpr (sizeof(T) == 4 && CI >= 16 && CI <= 48 && CI % 4 == 0 && CO <= 16) {
-        // per-(centre, tap) sums, then matrix-core products with W[f] (conv3p_forward_wide.hpp)
-        if (only_flagged == nullptr && st.ntap <= 31) {
-            const size_t wlds = forward_wide_lds(st.maxfull, st.ntap);
+    if constexpr (sizeof(T) == 4 && CI >= 16 && CI % 4 == 0 && CO <= 16) {
+        // transform + gather (conv3p_forward_taps.hpp): Z = X . W[f] for every point and tap, then 64 bytes per pair
+        if (only_flagged == nullptr && c.tap_scratch_ok) {
+            float *z = c.L.partials;
+            const size_t rows = (size_t)d.B * d.N;
             const BlockMap bm = make_blockmap(d);
+            const size_t glds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + 256 +
+                                a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * CO * 64 * 4);
             Scope sc(K_FORWARD, c.s);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(forward_wide_kernel<CI, CO>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-            hipLaunchKernelGGL((forward_wide_kernel<CI, CO>), dim3(grid_of(bm)), dim3(256), wlds, c.s, c.L.pts, c.L.boxes,
-                               S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, bm, output,
-                               c.act ? 1 : 0, st.window ? c.L.cmin : nullptr, S.tcount, c.ld);
+            hipLaunchKernelGGL((tap_transform_kernel<CI, CO>), dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, c.s, input,
+                               filter, z, rows, st.ntap, c.ld.in);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(tap_gather_kernel<CO>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+            hipLaunchKernelGGL((tap_gather_kernel<CO>), dim3(grid_of(bm)), dim3(256), glds, c.s, c.L.pts, c.L.boxes, S.count,
+                               S.pairs, S.segs, S.qsegs, z, st, d.N, d.ntiles, c.L.ngroups, bm, output, c.act ? 1 : 0,
+                               st.window ? c.L.cmin : nullptr, S.tcount, c.ld, sched_of(S));
             return hip_ok();
         }
     }
-#endif
     const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * ((CI * CO) | 1) * sizeof(T)) : 0) +
                        a16((size_t)st.ntap * kCntStride * sizeof(T)) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
@@ -455,7 +488,8 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((forward_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes,
                        S.count, S.pairs, S.segs, S.qsegs, input, filter, st, d.N, d.ntiles, c.L.ngroups, d.Cin, d.Cout,
-                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0, st.window ? c.L.cmin : nullptr, S.tcount, c.ld);
+                       bm, output, only_flagged, (CI > 0 && c.act) ? 1 : 0, st.window ? c.L.cmin : nullptr, S.tcount, c.ld,
+                       sched_of(S));
     return hip_ok();
 }
 
@@ -507,7 +541,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
             hipLaunchKernelGGL((backward_sparse_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), slds, c.s, c.L.pts, c.L.boxes,
                                S.count, S.pairs, S.segs, S.qsegs, S.qbm, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                                bm, grad_input, partials ? partials : c.L.partials, (c.act ? 1 : 0) | (c.accum ? 2 : 0), c.addend,
-                               st.window ? c.L.cmin : nullptr, c.ld, cap);
+                               st.window ? c.L.cmin : nullptr, c.ld, cap, sched_of(S));
             return hip_ok();
         }
     }
@@ -526,7 +560,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
                        ((CI > 0 && c.act) ? 1 : 0) | ((CI > 0 && c.accum) ? 2 : 0), c.addend, gen_slots,
-                       st.window ? c.L.cmin : nullptr, c.ld);
+                       st.window ? c.L.cmin : nullptr, c.ld, sched_of(S));
     return hip_ok();
 }
 
@@ -770,6 +804,7 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
         const size_t have = wh.persistent ? wh.scratch_cap : scratch;
         c.deep_scratch_ok = deep_shape((int)sizeof(T), d.Cin, d.Cout) &&
                             have >= deep_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
+        c.tap_scratch_ok = tap_forward_shape((int)sizeof(T), d.Cin, d.Cout) && have >= tap_forward_bytes(d);
     }
     const unsigned long long tag = stencil_tag(d, stride, (double)voxel, (int)sizeof(T));
     if (!wh.persistent) {
@@ -901,6 +936,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
     if (K > wh.nslots) return CONV3P_ERR_WORKSPACE;     // the stencils would evict each other
     hipStream_t s = static_cast<hipStream_t>(stream);
     SearchJobs<T> jobs;
+    SchedJobs sjobs;
     int njobs = 0;
     size_t lds = 0;
     bool any_window = false;
@@ -926,6 +962,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         j.segs = S.segs;
         j.qsegs = S.qsegs;
         j.qbm = S.qbm;
+        sjobs.job[njobs - 1] = SchedJob{S.segs, S.sched};
     }
     if (njobs == 0) return CONV3P_OK;
     const BlockMap bm = make_blockmap(c.d);
@@ -938,6 +975,8 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         };
         if (any_window) launch(search_multi_kernel<T, true>);    // window replication is a no-op for odd extents
         else launch(search_multi_kernel<T, false>);
+        hipLaunchKernelGGL(tile_sched_kernel, dim3(8, njobs), dim3(1024), 0, s, sjobs, c.d.B, c.d.ntiles, c.L.ngroups,
+                           bm.rounds * c.d.ntiles);
     }
     return hip_ok();
 }
@@ -1133,6 +1172,10 @@ size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, in
         const size_t need = (size_t)max_taps * ci * co * grid * (size_t)elem;                        \
         if (need > b) b = need;                                                                      \
     }
+    CONV3P_SMALL_SHAPES(X)
+#undef X
+#define X(ci, co)                                                                                    \
+    if (ci <= max_Cin && co <= max_Cout && tap_forward_shape(elem, ci, co) && tap_forward_bytes(d) > b) b = tap_forward_bytes(d);
     CONV3P_SMALL_SHAPES(X)
 #undef X
 #define X(ci, co)                                                                                    \

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
     const uint32_t *__restrict__ qbm, const T *__restrict__ grad_out, const T *__restrict__ input,
     const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, BlockMap bm, T *__restrict__ grad_input,
     T *__restrict__ partials, int act, const T *__restrict__ addend, const T *__restrict__ cmin, RowLd ld,
-    int cap)   // G rows (slots) the LDS allocation holds; >= 64, so every tap fits a round of its own
+    int cap,   // G rows (slots) the LDS allocation holds; >= 64, so every tap fits a round of its own
+    const uint32_t *__restrict__ sched)   // launch order of the tiles (tile_sched_kernel) or nullptr
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
     rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
 
     int b, qt;
-    const bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
+    const bool live = block_to_tile(bm, sched, ntiles, b, qt);   // uniform for the workgroup
     const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
     PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
     if (!live) me.idx = -1;

@@ -667,6 +667,90 @@ __global__ __launch_bounds__(256) void search_multi_kernel(const PointRec<T> *__
 }
 
 // ---------------------------------------------------------------------------------
+// tile_sched_kernel: launch order of the query tiles for the kernels that walk the pair lists.  A tile's cost follows
+// the length of its lists, and dense regions of a cloud give tiles of 2-4x the mean (rooms, stride 1: max 18 349 pairs
+// against a mean of 5 058); in Hilbert order such tiles are neighbours, land on the same few CUs and set the kernel's
+// duration.  The tiles of every XCD (clouds stay on their XCD, see BlockMap) are therefore issued LONGEST FIRST:
+//   sched[xcd * cap + i] = i-th tile (b * ntiles + qt) of that XCD, 0xFFFFFFFF past its last one; cap = rounds * ntiles
+// so that the heavy tiles start at once, one per CU, and the light ones fill in behind them.  A pure function of the
+// segment table: rebuilt after every search launch, the same for a cached and a fresh geometry.
+// One workgroup per (XCD, stencil); bitonic sort of (records descending, tile id ascending) keys in LDS, up to 4096
+// tiles per XCD (more: the BlockMap order is kept).  Tiles whose pair buffer overflowed search themselves: first.
+constexpr int kSchedTiles = 4096;
+struct SchedJob {
+    const uint2 *segs;
+    uint32_t *sched;
+};
+struct SchedJobs {
+    SchedJob job[kMaxJobs];
+};
+__global__ __launch_bounds__(1024) void tile_sched_kernel(SchedJobs jobs, int B, int ntiles, int ngroups, int cap)
+{
+    __shared__ unsigned long long keys[kSchedTiles];
+    const SchedJob &jb = jobs.job[blockIdx.y];
+    const int xcd = blockIdx.x;
+    const int nclouds = B > xcd ? (B - xcd + 7) / 8 : 0;
+    const int n = nclouds * ntiles;
+    uint32_t *out = jb.sched + (size_t)xcd * cap;
+    if (n > kSchedTiles) {
+        for (int i = threadIdx.x; i < cap; i += blockDim.x)
+            out[i] = i < n ? (uint32_t)((xcd + 8 * (i / ntiles)) * ntiles + i % ntiles) : 0xFFFFFFFFu;
+        return;
+    }
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        unsigned long long k = ~0ull;                        // padding sorts last
+        if (i < n) {
+            const uint32_t tile = (uint32_t)((xcd + 8 * (i / ntiles)) * ntiles + i % ntiles);
+            uint32_t recs = 0;
+            for (int g = 0; g < ngroups; ++g) {
+                const uint32_t y = jb.segs[(size_t)tile * ngroups + g].y;
+                recs = y == kSegOverflow || recs + y < recs ? 0xFFFFFFFEu : recs + y;
+            }
+            k = ((unsigned long long)(0xFFFFFFFFu - recs) << 32) | tile;
+        }
+        keys[i] = k;
+    }
+    for (int i = n + (int)threadIdx.x; i < cap; i += blockDim.x) out[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (n <= 1024) {
+        // rank sort: the keys are distinct (tile id in the low half), a key's rank is the number of smaller keys --
+        // n broadcast reads per thread and no further barrier (the models' sizes: 128 .. 512 tiles per XCD)
+        if ((int)threadIdx.x < n) {
+            const unsigned long long mine = keys[threadIdx.x];
+            int rank = 0;
+            for (int i = 0; i < n; ++i) rank += keys[i] < mine ? 1 : 0;
+            out[rank] = (uint32_t)mine;
+        }
+        return;
+    }
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < npad; t += blockDim.x) {
+                const int q = t ^ j;
+                if (q > t) {
+                    const unsigned long long a = keys[t], b = keys[q];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) { keys[t] = b; keys[q] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = (uint32_t)keys[i];
+}
+// (cloud, query tile) of a workgroup by the schedule (sched == nullptr: by the BlockMap)
+__device__ __forceinline__ bool block_to_tile(const BlockMap &m, const uint32_t *__restrict__ sched, int ntiles, int &cloud, int &qt)
+{
+    if (sched == nullptr) return block_to_cloud(m, cloud, qt);
+    const uint32_t t = sched[(size_t)(blockIdx.x & 7) * ((size_t)m.rounds * ntiles) + (blockIdx.x >> 3)];
+    if (t == 0xFFFFFFFFu) return false;
+    cloud = (int)(t / (uint32_t)ntiles);
+    qt = (int)(t - (uint32_t)cloud * (uint32_t)ntiles);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------
 // forward accumulate: out[i,c] = sum over pairs of W[f,k,c] * x[j,k] / count[i,f]  (.cpp:480-494)
 // One workgroup = one query tile; threads stride over the tile's pair segment (lane = pair).
 // Small path (CIN/COUT compile-time): each wave owns 16 centres, the 4 lanes {c, c+16, c+32, c+48}
@@ -688,7 +772,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     int act,   // act != 0 (small path only): store selu(out), the models' layer (pointcnn2_acsd.py:48-49)
     const T *__restrict__ cmin,   // per-cloud grid origin (window-mode stencils, overflow path only)
     const int32_t *__restrict__ tcount,   // populations tile-major [tile][tap][centre lane] (search_tile)
-    RowLd ld)
+    RowLd ld, const uint32_t *__restrict__ sched)   // sched: launch order of the tiles (tile_sched_kernel) or nullptr
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -714,7 +798,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense path: centre and sub-lane of this thread
 
     int b, qt;
-    if (!block_to_cloud(bm, b, qt)) return;   // uniform
+    if (!block_to_tile(bm, sched, ntiles, b, qt)) return;   // uniform
     if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
 #if CONV3P_ABLATE & 134217728
     long long ft[8];
@@ -977,7 +1061,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     int gen_slots,                           // generic path: number of grad_filter partial slots the workgroups
                                              // spread their atomics over (slot = workgroup % gen_slots)
     const T *__restrict__ cmin,              // per-cloud grid origin (window-mode stencils, overflow path only)
-    RowLd ld)
+    RowLd ld, const uint32_t *__restrict__ sched)   // sched: launch order of the tiles (tile_sched_kernel) or nullptr
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -1038,7 +1122,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     }
 
     int b, qt;
-    bool live = block_to_cloud(bm, b, qt);   // uniform for the workgroup
+    bool live = block_to_tile(bm, sched, ntiles, b, qt);   // uniform for the workgroup
     if (live && only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) live = false;   // deep path did it
     const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
     PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
@@ -1540,4 +1624,4 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T *src, T *dst, si
 }  // namespace conv3p
 
 #include "conv3p_backward_sparse.hpp"
-#include "conv3p_forward_wide.hpp"
+#include "conv3p_forward_taps.hpp"
