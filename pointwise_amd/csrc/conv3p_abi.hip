@@ -965,6 +965,17 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         sjobs.job[njobs - 1] = SchedJob{S.segs, S.sched};
     }
     if (njobs == 0) return CONV3P_OK;
+#ifndef CONV3P_DEV_JOBS_IN_ORDER
+    // widest stencil first (blockIdx.y ascending is the dispatch order): its boxes meet the most candidate tiles, its
+    // workgroups run longest -- started last they would be the launch's tail
+    for (int a = 1; a < njobs; ++a)
+        for (int b2 = a; b2 > 0; --b2) {
+            auto vol = [](const SearchJob<T> &j) { return (long long)j.st.step[0] * j.st.step[1] * j.st.step[2]; };
+            if (vol(jobs.job[b2]) <= vol(jobs.job[b2 - 1])) break;
+            std::swap(jobs.job[b2], jobs.job[b2 - 1]);
+            std::swap(sjobs.job[b2], sjobs.job[b2 - 1]);
+        }
+#endif
     const BlockMap bm = make_blockmap(c.d);
     {
         Scope sc(K_SEARCH, s);

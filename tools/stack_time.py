@@ -10,6 +10,7 @@ def run(name, B, N, cin, num_class, kind, steps=30):
     Xs = [torch.from_numpy(synth.features(B, N, cin, 50 + i, points=p.cpu().numpy())).to(dev) for i, p in enumerate(Ps)]
     st = stack.Conv3pStack(cin, num_class, device=dev, seed=3)
     print('sparse neighbourhoods hint:', st.tune(Ps[0]))
+    if os.environ.get('FORCE_HINT'): st.sparse_neighbourhoods = os.environ['FORCE_HINT'] == '1'; print('forced hint', st.sparse_neighbourhoods)
     nup = 1 if num_class is not None else 4
     cup = num_class if num_class is not None else stack.HIDDEN
     ups = [torch.from_numpy(synth.upstream_grad(B, N, cup, 60 + i)).to(dev) for i in range(nup)]

@@ -17,7 +17,7 @@ def per_kernel(db, counter):
     out = {}
     q = "select %s, avg(value), count(*) from counters_collection where counter_name = ? group by %s" % (ki, ki)
     for name, avg, n in c.execute(q, (counter,)):
-        key = name.split("(")[0].replace("void conv3p::", "").split("<")[0]
+        key = name.split("(")[0].replace("void ", "").replace("conv3p::", "").split("<")[0]
         key = {"backward_sparse_kernel": "backward_kernel"}.get(key, key)   # bench.py's kind: both backward kernels
         a = out.setdefault(key, [0.0, 0])
         a[0] += avg * n

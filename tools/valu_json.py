@@ -14,7 +14,7 @@ for name, cname, n, avg in db.execute(
         "select %s, counter_name, count(*), avg(value) from counters_collection group by %s, counter_name" % (ki, ki)):
     if "conv3p::" not in name:
         continue
-    key = name.split("(")[0].replace("void conv3p::", "").split("<")[0]
+    key = name.split("(")[0].replace("void ", "").replace("conv3p::", "").split("<")[0]
     key = {"search_multi_kernel": "search_kernel", "prep_sort_kernel": "prep_kernel",
            "reduce_multi_kernel": "reduce_partials_kernel", "backward_sparse_kernel": "backward_kernel"}.get(key, key)
     a = acc.setdefault(key, {}).setdefault(cname, [0.0, 0])
