@@ -552,7 +552,7 @@ def test_deep_channel_path_is_used_and_reproducible(dev, ci, co):
 def test_pair_buffer_overflow_falls_back_correctly(dev):
     """A cache configured with a tiny pair capacity overflows: the small-channel kernels search the tile
     themselves, the deep path hands flagged tiles to the generic kernel.  Results must still be exact."""
-    for ci, co in ((9, 9), (32, 64)):
+    for ci, co in ((9, 9), (32, 64), (36, 13)):   # (36 -> 13: the transform + gather forward and the populated-rows backward)
         B, N = 2, 300
         P, X, W, dY = make_case("room", B, N, ci, co, seed=970)
         cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, pairs_per_point=4, max_cin=ci,
@@ -561,6 +561,42 @@ def test_pair_buffer_overflow_falls_back_correctly(dev):
         assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, (1, 1, 1), VOX)) <= 1e-5
         dx_ref, dw_ref = oracle.backward(dY, P, X, W, (1, 1, 1), VOX)
         assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
+
+
+def test_transform_gather_forward_dilated_ragged_stateless(dev):
+    """36 -> 13 (tap_transform_kernel + tap_gather_kernel): dilated and undilated stencils, N not a multiple of the
+    tile or of the transform's 32-point blocks; against the oracle, and the stateless call (workspace sized by
+    conv3p_workspace_bytes, Z included) bit for bit against the cached one."""
+    B, N, ci, co = 3, 777, 36, 13
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=1201)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tP, tX, tW = t(P), t(X), t(W)
+    for s in ((1, 1, 1), (2, 2, 2), (3, 1, 2)):
+        cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
+        y = op.conv3p(tP, tX, tW, s, VOX, cache=cache)
+        assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, s, VOX)) <= 1e-5
+        y3 = op.conv3p(tP, tX, tW, s, VOX)              # stateless workspace (sized by conv3p_workspace_bytes)
+        assert torch.equal(y, y3)
+
+
+def test_tile_schedule_is_a_permutation_and_results_do_not_depend_on_it(dev):
+    """Clouds with a dense cluster (tiles of very different list lengths): every tile is processed exactly once whatever
+    the launch order -- outputs equal the oracle's, two caches built independently agree bit for bit, also with more
+    clouds than XCDs (several rounds per XCD) and with a single tile per cloud."""
+    rng = np.random.default_rng(77)
+    for B, N in ((11, 500), (3, 64), (1, 1000)):
+        P = synth.room_like(B, N, 1300 + B)
+        P[:, : N // 4] = P[:, :1] + 0.02 * rng.standard_normal((B, N // 4, 3)).astype(np.float32)   # a dense blob
+        X = synth.features(B, N, 9, 1301, points=P)
+        W = synth.filter_weights(3, 3, 3, 9, 9, 1302)
+        dY = synth.upstream_grad(B, N, 9, 1303)
+        a = _both(dev, op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=9, max_cout=9), P, X, W, dY, (1, 1, 1))
+        b = _both(dev, op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=9, max_cout=9), P, X, W, dY, (1, 1, 1))
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        assert rel_err(a[0].cpu().numpy(), oracle.forward(P, X, W, (1, 1, 1), VOX)) <= 1e-5
+        dx_ref, dw_ref = oracle.backward(dY, P, X, W, (1, 1, 1), VOX)
+        assert rel_err(a[1].cpu().numpy(), dx_ref) <= 1e-5 and rel_err(a[2].cpu().numpy(), dw_ref) <= 2e-5
 
 
 # ------------------------------------------------------------------ fused conv3p + SELU layer ops
