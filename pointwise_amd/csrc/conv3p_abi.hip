@@ -608,6 +608,8 @@ struct DeepScratch {   // carved from the per-call scratch region
     unsigned long long *tap_cmask;   // [tiles][F] centres with records of the backward tap: the rows of G_f' that exist
     uint32_t *sched;       // [8][sched_cap] launch order of the tiles per XCD (deep_sched_kernel)
     int sched_cap;
+    uint2 *dsegs;          // [tiles] {first slot in tap_meta, records} of every tile (deep_order; all search groups together)
+    uint32_t *meta_cursor; // [B] slot allocator of tap_meta for tiles searched in several groups (N > 8192)
     uint32_t *tap_total;   // [64] pairs per backward tap, then [1] number of work items  (deep_plan_kernel)
     uint2 *tap_rng;        // [64] partial slots of each tap
     uint4 *items;          // [kDwItems + 64] deep_dw_kernel work items
@@ -633,6 +635,8 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     s.tap_cmask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * d.ntap * 8));
     s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
     s.sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
+    s.dsegs = reinterpret_cast<uint2 *>(take((size_t)d.B * d.ntiles * 8));
+    s.meta_cursor = reinterpret_cast<uint32_t *>(take((size_t)d.B * 4));
     s.tap_total = reinterpret_cast<uint32_t *>(take(65 * 4));
     s.tap_rng = reinterpret_cast<uint2 *>(take(64 * 8));
     s.items = reinterpret_cast<uint4 *>(take((size_t)(kDwItems + 64) * 16));
@@ -649,13 +653,18 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     const Dims &d = c.d;
     if (d.ntap > 64) return CONV3P_ERR_UNSUPPORTED;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = (size_t)(2 + 4 * kOrderR + 64) * d.ntap * 4 + 256;
+    const int ng = c.L.ngroups;
+    const size_t lds = (size_t)(2 + 4 * kOrderR + 64) * d.ntap * 4 + 256 + (size_t)(2 * 64 * ng + 1 + 8) * 4;
+    if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     Scope sc(K_DEEP_ORDER, c.s);
     if (BWD) TRY(zero_async(ds.tap_total, 65 * 4, c.s));
+    if (ng > 1) TRY(zero_async(ds.meta_cursor, (size_t)d.B * 4, c.s));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_order_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(deep_order_kernel<BWD>, dim3((unsigned)(d.B * d.ntiles)), dim3(256), lds, c.s, c.L.pts, S.count,
-                       S.pairs, S.segs, d.N, d.ntiles, d.ntap, ds.tap_meta, ds.tap_off, ds.tile_flag,
+                       S.pairs, S.segs, d.N, d.ntiles, d.ntap, ng, S.qsegs, ds.dsegs, ds.meta_cursor, c.L.pairs_per_cloud,
+                       ds.tap_meta, ds.tap_off, ds.tile_flag,
                        BWD ? ds.tap_total : nullptr, BWD ? ds.pop_mask : nullptr, ds.tap_split, BWD ? ds.tap_cmask : nullptr);
-    hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, S.segs, d.B, d.ntiles, ds.sched_cap, ds.sched);
+    hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, ds.dsegs, d.B, d.ntiles, ds.sched_cap, ds.sched);
     if (BWD)
         hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.pop_mask, d.ntap, d.B * d.ntiles, kDwItems,
                            ds.items, ds.tap_rng, ds.tap_total + 64);
@@ -674,7 +683,7 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
     Scope sc(K_DEEP_GEMM, c.s);
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs, S.segs, src, Bm, d.N, d.ntiles,
+        hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, S.pairs, ds.dsegs, src, Bm, d.N, d.ntiles,
                            d.ntap, ds.sched, ds.sched_cap, out, ds.tap_meta, ds.tap_off, ds.tile_flag, kreal, nreal, gbuf, xin,
                            ds.tap_split, ds.tap_cmask);
     };
@@ -891,7 +900,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     if (c.strided) return CONV3P_ERR_UNSUPPORTED;   // (a register-path shape whose LDS did not fit)
     if constexpr (sizeof(T) == 4) {
         int cip = 0, cop = 0;
-        if (c.L.ngroups == 1 && c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {
+        if (c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {
 #define X(ci, co)                                                                                    \
     if (cip == ci && cop == co) {                                                                    \
         int rc = deep_forward<ci, co>(c, input, filter, output);                                     \
@@ -1089,7 +1098,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
         return backward_split_36_13<T>(c, grad_out, input, filter, grad_input, grad_filter);
     if constexpr (sizeof(T) == 4) {
         int cip = 0, cop = 0;
-        if (rc == CONV3P_ERR_UNSUPPORTED && c.L.ngroups == 1 && c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {
+        if (rc == CONV3P_ERR_UNSUPPORTED && c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {
 #define X(ci, co)                                                                                    \
     if (cip == ci && cop == co) {                                                                    \
         int drc = deep_backward<ci, co>(c, grad_out, input, filter, grad_input, grad_filter);        \

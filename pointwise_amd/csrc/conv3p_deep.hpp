@@ -100,6 +100,11 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
                                                          const int32_t *__restrict__ count,
                                                          const PairEntry *__restrict__ pairs,
                                                          const uint2 *__restrict__ segs, int N, int ntiles, int ntap,
+                                                         int ngroups,                        // segments per tile (search groups)
+                                                         const uint2 *__restrict__ qsegs,    // per (tile, group, centre) sub-lists (ngroups > 1 only)
+                                                         uint2 *__restrict__ dsegs,          // out [tile]: {first slot of the tile in tap_meta, records} or kSegOverflow
+                                                         uint32_t *__restrict__ meta_cursor, // [clouds] slot allocator of tap_meta (ngroups > 1 only; zeroed by the host)
+                                                         uint32_t pairs_per_cloud,
                                                          uint2 *__restrict__ tap_meta,
                                                          uint32_t *__restrict__ tap_off,
                                                          uint8_t *__restrict__ tile_flag,
@@ -118,9 +123,59 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
     const size_t tile = blockIdx.x;
     const int32_t *cnt_cloud = count + (tile / (size_t)ntiles) * (size_t)N * ntap;
     if (threadIdx.x < 64) qorig[threadIdx.x] = pts[tile * kTile + threadIdx.x].idx;
-    const uint2 tseg = segs[tile];                                  // ngroups == 1 on this path (host checks)
+    // The tile's records.  One search group (N <= 8192): its single segment of `pairs`, centre-major.  Several groups
+    // (one segment per 128 candidate tiles, each centre-major on its own): read as ONE centre-major list -- centre 0's
+    // sub-lists of all groups, then centre 1's, ... -- through a table of the 64 x ngroups sub-lists (first virtual
+    // index, address); the tap-major order written below is then centre-major inside every tap like the single-group
+    // one, which the quarter points and deep_gemm's segmented sums rely on.  Their slots in tap_meta come from a
+    // per-cloud allocator (the groups' own segments are not adjacent); the placement does not enter any result.
+    uint32_t *vstart = hist + (size_t)ntap * 64;                    // [64 * ngroups + 1]   (ngroups > 1)
+    uint32_t *vaddr = vstart + 64 * ngroups + 1;                    // [64 * ngroups]
+    uint32_t *wsum = vaddr + 64 * ngroups;                          // [4] + [1] slot base + [1] overflow
     uint32_t *toff = tap_off + tile * (size_t)(ntap + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint2 tseg;
+    const int nsub = 64 * ngroups;
+    if (ngroups == 1) {
+        tseg = segs[tile];
+    } else {
+        bool ovf = false;
+        for (int g = 0; g < ngroups; ++g) ovf |= segs[tile * ngroups + g].y == kSegOverflow;
+        const int per = (nsub + 255) / 256;                         // consecutive sub-lists per thread
+        uint32_t local = 0;
+        for (int e = 0; e < per; ++e) {
+            const int sidx = (int)tid * per + e;                    // sub-list (centre q, group g) = (sidx / ngroups, sidx % ngroups)
+            if (sidx < nsub && !ovf) {
+                const uint2 qs = qsegs[((size_t)tile * ngroups + (sidx % ngroups)) * 64 + (sidx / ngroups)];
+                vaddr[sidx] = qs.x;
+                vstart[sidx + 1] = qs.y;                            // (lengths for now)
+                local += qs.y;
+            }
+        }
+        int wtot;
+        const int excl = wave_excl_scan((int)local, wtot);
+        if (lane == 63) wsum[wave] = (uint32_t)wtot;
+        __syncthreads();
+        uint32_t before = (uint32_t)excl;
+        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+        const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();                                            // (wsum is reused below)
+        for (int e = 0; e < per; ++e) {
+            const int sidx = (int)tid * per + e;
+            if (sidx < nsub && !ovf) {
+                const uint32_t len = vstart[sidx + 1];
+                vstart[sidx + 1] = before + len;                    // inclusive end = next start (own entries only: no race)
+                before += len;
+            }
+        }
+        if (tid == 0) {
+            vstart[0] = 0;
+            wsum[4] = ovf ? 0u : (uint32_t)(tile / (size_t)ntiles) * pairs_per_cloud + atomicAdd(&meta_cursor[tile / (size_t)ntiles], total);
+        }
+        __syncthreads();
+        tseg = make_uint2(wsum[4], ovf ? kSegOverflow : total);
+    }
+    if (tid == 0) dsegs[tile] = tseg;
     if (tseg.y == kSegOverflow) {
         for (uint32_t f = tid; f <= (uint32_t)ntap; f += 256) toff[f] = 0;
         if (tid == 0) {
@@ -132,8 +187,18 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
         return;
     }
     if (tid == 0) tile_flag[tile] = 0;
-    const PairEntry *seg = pairs + tseg.x;
+    const PairEntry *seg = pairs + tseg.x;                          // (single group)
     const uint32_t n = tseg.y;
+    // record i of the tile's centre-major list
+    auto record = [&](uint32_t i) -> PairEntry {
+        if (ngroups == 1) return seg[i];
+        int lo = 0, hi = nsub;                                      // last sub-list whose first index is <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (vstart[mid] <= i) lo = mid; else hi = mid;
+        }
+        return pairs[vaddr[lo] + (i - vstart[lo])];
+    };
     auto zero_wcnt = [&]() {
         for (uint32_t e = tid; e < (uint32_t)(4 * R * ntap); e += 256) wcnt[e] = 0;
     };
@@ -152,7 +217,7 @@ __global__ __launch_bounds__(256) void deep_order_kernel(const PointRec<float> *
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const uint32_t i = s0 + (uint32_t)u * 256u + tid;
-            en[u] = seg[i < n ? i : 0u];
+            en[u] = record(i < n ? i : 0u);
         }
         uint32_t pop[R];
 #pragma unroll

@@ -549,6 +549,35 @@ def test_deep_channel_path_is_used_and_reproducible(dev, ci, co):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("N,kind", [(9000, "room"), (16384 + 70, "modelnet")])
+def test_deep_channel_path_beyond_one_search_group(dev, N, kind):
+    """Clouds of more than 8192 points are searched in several groups of candidate tiles (one pair segment per group);
+    the matrix-core path reads them as one centre-major list.  32 -> 64 channels at N = 9000 (2 groups) and
+    N = 16454 (3 groups, ragged): the deep kernels run (not the global-atomics ones), results match the oracle and
+    are bitwise reproducible."""
+    lib = _lib.load()
+    ci, co = 32, 64
+    P, X, W, dY = make_case(kind, 1, N, ci, co, seed=1400)
+    lib.conv3p_profile_reset()
+    lib.conv3p_profile_enable(1)
+    a = _both(dev, None, P, X, W, dY, (1, 1, 1))
+    torch.cuda.synchronize()
+    lib.conv3p_profile_enable(0)
+    seen = {}
+    for k in range(lib.conv3p_profile_kinds()):
+        n = ctypes.c_uint64(0)
+        lib.conv3p_profile_read(k, ctypes.byref(n), None)
+        seen[lib.conv3p_profile_name(k).decode()] = n.value
+    lib.conv3p_profile_reset()
+    assert seen.get("deep_gemm_kernel", 0) == 2 and seen.get("deep_dw_kernel", 0) == 1, seen
+    b = _both(dev, None, P, X, W, dY, (1, 1, 1))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert rel_err(a[0].cpu().numpy(), oracle.forward(P, X, W, (1, 1, 1), VOX, nthreads=8)) <= 1e-5
+    dx_ref, dw_ref = oracle.backward(dY, P, X, W, (1, 1, 1), VOX, nthreads=1)
+    assert rel_err(a[1].cpu().numpy(), dx_ref) <= 1e-5 and rel_err(a[2].cpu().numpy(), dw_ref) <= 5e-5
+
+
 def test_pair_buffer_overflow_falls_back_correctly(dev):
     """A cache configured with a tiny pair capacity overflows: the small-channel kernels search the tile
     themselves, the deep path hands flagged tiles to the generic kernel.  Results must still be exact."""
