@@ -1211,7 +1211,10 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     // registers; the record of step k+kDepth-1 and the dY row + population of step k+kDepth-2 are in
                     // flight while step k runs.  (Rotating slots by register copies made every step wait for the
                     // newest load -- a copy reads its destination -- so that "pipeline" drained the queue every step.)
-                    constexpr int kDepth = 4;   // measured: 8 slots (whole lists requested up front) is 3 % slower on cfg2
+#ifndef CONV3P_BWD_DEPTH
+#define CONV3P_BWD_DEPTH 4
+#endif
+                    constexpr int kDepth = CONV3P_BWD_DEPTH;   // measured: 8 slots (whole lists requested up front) is 3 % slower on cfg2
                     PairEntry rec[kDepth];
                     bool lv[kDepth];
                     int cn[kDepth];

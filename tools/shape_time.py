@@ -12,7 +12,8 @@ dev = torch.device("cuda:0")
 P = (synth.room_like if kind == "room" else synth.modelnet_like)(B, N, 40)
 t = lambda a: torch.from_numpy(a).to(dev)
 tp, tx, tw, tdy = t(P), t(synth.features(B, N, ci, 1, points=P)), t(synth.filter_weights(3, 3, 3, ci, co, 2)), t(synth.upstream_grad(B, N, co, 3))
-cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
+cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co,
+                         sparse_neighbourhoods=os.environ.get('FORCE_HINT') == '1')
 f = lambda: op.conv3p(tp, tx, tw, S3, 0.1, cache=cache)
 g = lambda: op.conv3p_grad(tdy, tp, tx, tw, S3, 0.1, cache=cache)
 for fn in (f, g): fn(); fn()
