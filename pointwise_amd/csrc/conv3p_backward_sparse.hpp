@@ -28,6 +28,9 @@
 #ifndef CONV3P_SP_DEPTH_WIDE
 #define CONV3P_SP_DEPTH_WIDE 4   // phase A gather depth of the >= 16-input layers (2 waves per SIMD: 256 registers)
 #endif
+#ifndef CONV3P_SP_TURNS
+#define CONV3P_SP_TURNS 1   // developer A/B: 0 = equal-tap sub-lanes merged by lane swaps before one read-modify-write
+#endif
 #ifndef CONV3P_SP_CHSPLIT
 #define CONV3P_SP_CHSPLIT 1   // developer A/B: 0 = a centre's sub-lanes take different records (merged by lane swaps)
 #endif
@@ -264,6 +267,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
                     lv[sl] = live_rec(rec[sl], i);
                     row[sl] = slot_of(lv[sl] ? code_bwd(rec[sl].code) : (uint32_t)t0, lt_cq);
                     cn[sl] = cnt_cloud[lv[sl] && !(CONV3P_SP_ABLATE & 32) ? (size_t)rec[sl].cand * st.ntap + code_bwd(rec[sl].code) : (size_t)0];
+                    if (CONV3P_SP_ABLATE & 64) {   // developer: one 16-byte load instead of the whole row (timing only)
+                        T four[4];
+                        RowLoader<T, 4>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy, four);
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) val[sl][c] = four[c & 3];
+                    } else
                     RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] && !(CONV3P_SP_ABLATE & 32) ? rec[sl].cand : 0u) * ld.dy, val[sl]);
                 };
 #pragma unroll
@@ -291,6 +300,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
 #pragma unroll
                             for (int c = 0; c < COUT; ++c) v[c] *= rcpb;
                         }
+#if CONV3P_SP_TURNS
+                        // Sub-lanes of one centre that meet on a tap take TURNS at its row of G, lower sub-lane first:
+                        // turn = number of lower sub-lanes with the same tap (three swaps of the tap alone); a wave's
+                        // LDS accesses execute in program order, so turn p adds to what turn p - 1 wrote.  (Before:
+                        // the lower lane absorbed the higher one's 9 values through lane swaps -- 40 swaps and 75
+                        // selects per step, half of phase A's 290 vector instructions per step, and phase A is bound
+                        // by exactly that count: 4 waves per SIMD x 290 x 4 cycles = the measured 1.9 us per step.)
+                        {
+                            const uint32_t mine_fb = pending ? fb : kNoTap;
+                            const uint32_t f1 = lane_xor16(mine_fb), f2 = lane_xor32(mine_fb), f3 = lane_xor32(f1);
+                            const int turn = ((sub & 1) && f1 == mine_fb ? 1 : 0) + ((sub & 2) && f2 == mine_fb ? 1 : 0) +
+                                             (sub >= 2 && f3 == mine_fb ? 1 : 0);
+                            T *grow = G + (size_t)row[j] * COUT;
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) {
+                                if (p > 0 && !__any(pending && turn >= p)) break;
+                                if (pending && turn == p) {
+#pragma unroll
+                                    for (int c = 0; c < COUT; ++c) grow[c] += v[c];
+                                }
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            }
+                        }
+#else
                         // sub-lanes of one centre that meet on a tap: the lower one absorbs the higher (fixed order)
 #pragma unroll
                         for (int step = 0; step < 3; ++step) {
@@ -316,6 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
 #pragma unroll
                             for (int c = 0; c < COUT; ++c) grow[c] += v[c];
                         }
+#endif
                         i += 4;
                     }
                 }

@@ -1211,6 +1211,9 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     // registers; the record of step k+kDepth-1 and the dY row + population of step k+kDepth-2 are in
                     // flight while step k runs.  (Rotating slots by register copies made every step wait for the
                     // newest load -- a copy reads its destination -- so that "pipeline" drained the queue every step.)
+#ifndef CONV3P_BWD_TURNS
+#define CONV3P_BWD_TURNS 1   // developer A/B: 0 = equal-tap sub-lanes merged by lane swaps before one read-modify-write
+#endif
 #ifndef CONV3P_BWD_DEPTH
 #define CONV3P_BWD_DEPTH 4
 #endif
@@ -1269,6 +1272,29 @@ __global__ __launch_bounds__(256) void backward_kernel(
                                 }
                                 pending = false;
                             }
+#if CONV3P_BWD_TURNS
+                            // Sub-lanes of one centre that target the same tap take TURNS at the tap's G entries, lower
+                            // sub-lane first: turn = number of lower sub-lanes with the same tap (three swaps of the tap
+                            // alone); a wave's LDS accesses execute in program order, so turn p adds to what turn p - 1
+                            // wrote -- race-free and in a fixed order.  (Until round 3 the lower lane absorbed the higher
+                            // one's values through lane swaps first: 40 swaps and 75 selects per step.)
+                            {
+                                const uint32_t mine_fb = pending ? fb : kNoTap;
+                                const uint32_t f1 = lane_xor16(mine_fb), f2 = lane_xor32(mine_fb), f3 = lane_xor32(f1);
+                                const int turn = ((sub & 1) && f1 == mine_fb ? 1 : 0) + ((sub & 2) && f2 == mine_fb ? 1 : 0) +
+                                                 (sub >= 2 && f3 == mine_fb ? 1 : 0);
+                                T *grow = G + ((size_t)(pending ? fb : 0u) * COUT) * kCntStride + cq;
+#pragma unroll
+                                for (int p = 0; p < 4; ++p) {
+                                    if (p > 0 && !__any(pending && turn >= p)) break;
+                                    if (pending && turn == p) {
+#pragma unroll
+                                        for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += v[c];
+                                    }
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                }
+                            }
+#else
                             // Sub-lanes of one centre that target the same tap are merged first (fixed order:
                             // partner distance 16, 32, 48 lanes; the lower sub-lane absorbs the higher one), so a
                             // single race-free read-modify-write round follows.  Neighbouring candidates usually
@@ -1297,6 +1323,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
 #pragma unroll
                                 for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += v[c];
                             }
+#endif
                             i += 4;
                         }
                     }
