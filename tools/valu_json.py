@@ -15,10 +15,13 @@ for name, cname, n, avg in db.execute(
     if "conv3p::" not in name:
         continue
     key = name.split("(")[0].replace("void ", "").replace("conv3p::", "").split("<")[0]
-    key = {"search_multi_kernel": "search_kernel", "prep_sort_kernel": "prep_kernel",
+    key = {"prep_sort_kernel": "prep_kernel",
            "reduce_multi_kernel": "reduce_partials_kernel", "backward_sparse_kernel": "backward_kernel"}.get(key, key)
     a = acc.setdefault(key, {}).setdefault(cname, [0.0, 0])
     a[0] += avg * n
     a[1] += n
-# search_multi_kernel runs all strides of a step in one launch: bench.py's "search_kernel" kind times exactly that
+# search_multi_kernel runs all strides of a step in one launch: bench.py's "search_kernel" kind times exactly that (the
+# single-stride search_kernel launches of a run are its first step's, before any prefetch)
+if "search_multi_kernel" in acc:
+    acc["search_kernel"] = acc.pop("search_multi_kernel")
 print(json.dumps({k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in sorted(acc.items())}, indent=1))
