@@ -340,7 +340,7 @@ class GeometryPrefetch:
         main = torch.cuda.current_stream(self.dev)
         k = self.k
         if self.pending[k] is not P:    # first step: build it in line
-            op.cache_prepare(P, (3, 3, 3), (1, 1, 1), stack.VOXEL, self.caches[k])
+            op.cache_prepare(P, (3, 3, 3), (1, 1, 1), stack.VOXEL, self.caches[k], deep_orders=True)
             self.pending[k] = P
         else:
             main.wait_event(self.ready[k])
@@ -353,7 +353,7 @@ class GeometryPrefetch:
         o = self.k ^ 1
         self.side.wait_event(self.done[o])
         with torch.cuda.stream(self.side):
-            op.cache_prepare(P_next, (3, 3, 3), (1, 1, 1), stack.VOXEL, self.caches[o], stream=self.side)
+            op.cache_prepare(P_next, (3, 3, 3), (1, 1, 1), stack.VOXEL, self.caches[o], stream=self.side, deep_orders=True)
             self.ready[o].record(self.side)
         self.pending[o] = P_next
 

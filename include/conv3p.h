@@ -136,6 +136,13 @@ typedef struct conv3p_cache_config {
  * +30 % on those kernels).  Results are the reference's either way (same decisions, tolerance of the op); they
  * are NOT bitwise the same with and without the hint (different summation orders). */
 #define CONV3P_CACHE_SPARSE_NEIGHBOURHOODS 2
+/* conv3p_cache_prepare_f32 only: besides the geometry, also build the two record orders (by forward tap, by backward
+ * tap) that the matrix-core path of the wide layers (more than 16 channels on either side, fp32) derives from it -- about
+ * 7 % of such a layer's forward+backward.  The next forward / backward on the same points in this cache (called with
+ * CONV3P_CACHE_POINTS_UNCHANGED) then finds them in the cache's scratch region; any other use of the cache in between
+ * (another stencil's wide layer, a narrow layer) simply rebuilds them.  Needs a cache sized for a wide layer
+ * (max_Cin / max_Cout of conv3p_cache_config); CONV3P_ERR_WORKSPACE otherwise.  A performance hint only. */
+#define CONV3P_CACHE_PREPARE_DEEP_ORDERS 4
 
 size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_config *cfg);
 /* Drop the host-side bookkeeping of a cache buffer (call before freeing it). */

@@ -64,11 +64,13 @@ class NeighborCache:
             raise Conv3pInvalidArgument("bad neighbour-cache configuration")
         self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
 
-    def cfg_ptr(self, points_unchanged):
+    def cfg_ptr(self, points_unchanged, deep_orders=False):
         """Address of the config struct for one call; points_unchanged = the caller's promise that `points`
-        holds the same bytes as at the previous cached call (CONV3P_CACHE_POINTS_UNCHANGED)."""
+        holds the same bytes as at the previous cached call (CONV3P_CACHE_POINTS_UNCHANGED); deep_orders (prepare
+        only) = CONV3P_CACHE_PREPARE_DEEP_ORDERS."""
         self.cfg.flags = (_lib.CACHE_POINTS_UNCHANGED if points_unchanged else 0) | \
-                         (_lib.CACHE_SPARSE_NEIGHBOURHOODS if self.sparse_neighbourhoods else 0)
+                         (_lib.CACHE_SPARSE_NEIGHBOURHOODS if self.sparse_neighbourhoods else 0) | \
+                         (_lib.CACHE_PREPARE_DEEP_ORDERS if deep_orders else 0)
         return ctypes.addressof(self.cfg)
 
     def fits(self, B, N, dtype, device, ntap, cin, cout):
@@ -249,9 +251,11 @@ def conv3p_layer_grad(grad_from_next, points, input, filter, stride, voxel_size,
                        cache=cache, points_unchanged=points_unchanged, _fused_selu=True, _grad_addend=grad_addend)
 
 
-def cache_prepare(points, filter_zyx, stride, voxel_size, cache, points_unchanged=False, stream=None):
+def cache_prepare(points, filter_zyx, stride, voxel_size, cache, points_unchanged=False, stream=None,
+                  deep_orders=False):
     """Build / re-validate the geometry of one stencil in `cache` (conv3p_cache_prepare_*), on `stream`
-    (default: the current stream)."""
+    (default: the current stream).  deep_orders: also the record orders of the matrix-core path (wide fp32 layers), so
+    that the layer's forward / backward on these points (points_unchanged=True) need not build them."""
     lib = _lib.load()
     _require(points.dim() == 3 and points.shape[2] == 3, "Conv3p expects (batch_size, num_points, 3) points shape")
     dev = _check_device(points)
@@ -266,8 +270,8 @@ def cache_prepare(points, filter_zyx, stride, voxel_size, cache, points_unchange
     with torch.cuda.device(dev):
         st = stream if stream is not None else torch.cuda.current_stream(dev)
         _call(getattr(lib, "conv3p_cache_prepare_" + sfx), points.data_ptr(), ctypes.cast(s3, ctypes.c_void_p),
-              creal(vox), B, N, fz, fy, fx, cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(points_unchanged),
-              st.cuda_stream)
+              creal(vox), B, N, fz, fy, fx, cache.buf.data_ptr(), cache.nbytes,
+              cache.cfg_ptr(points_unchanged, deep_orders=deep_orders and points.dtype == torch.float32), st.cuda_stream)
 
 
 def cache_prepare_multi(points, filter_zyx, strides, voxel_size, cache, points_unchanged=False, stream=None):

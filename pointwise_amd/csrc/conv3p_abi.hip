@@ -327,6 +327,9 @@ template <typename T> struct Call {
     hipStream_t s;
     bool deep_scratch_ok = false;  // the scratch region can hold the deep path's side arrays
     bool tap_scratch_ok = false;   // ... the transform + gather forward's Z array
+    bool order_ok[2] = {false, false};   // the deep path's forward / backward record order of this geometry is in the scratch
+    void *cache_key = nullptr;     // persistent cache the call runs in (host bookkeeping of the record orders)
+    uint64_t gen = 0;
     bool evicted_hinted = false;   // slot re-assigned to a new stencil while prep is skipped: reset its allocators
     bool skip_prep = false;     // caller promised unchanged points
     bool skip_search = false;   // ... and this slot's lists were already enqueued for them
@@ -618,7 +621,10 @@ struct DeepScratch {   // carved from the per-call scratch region
     size_t bytes;
 };
 
-DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
+// The record orders (deep_order_kernel) come FIRST and twice -- forward taps and backward taps -- at offsets that do not
+// depend on the channel counts: a geometry prefetch (CONV3P_CACHE_PREPARE_DEEP_ORDERS) builds both ahead of the
+// layer's calls, which then find them in place.  `which`: 0 = the forward's set, 1 = the backward's.
+DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base, int which, size_t *order_bytes = nullptr)
 {
     DeepScratch s{};
     size_t off = 0;
@@ -626,32 +632,50 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base)
     auto take = [&](size_t n) { char *r = p ? p + off : nullptr; off += up(n); return r; };
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
     const size_t cip = (size_t)deep_pad(d.Cin), cop = (size_t)deep_pad(d.Cout);
-    s.wt = reinterpret_cast<float *>(take((size_t)d.ntap * cip * cop * 4));
-    s.tap_meta = reinterpret_cast<uint2 *>(take(pair_slots * 8));
-    s.tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
-    s.tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
-    s.pop_mask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * 8));
-    s.tap_split = reinterpret_cast<uint4 *>(take((size_t)d.B * d.ntiles * d.ntap * 16));
-    s.tap_cmask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * d.ntap * 8));
     s.sched_cap = ((d.B + 7) / 8) * d.ntiles;
-    s.sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
-    s.dsegs = reinterpret_cast<uint2 *>(take((size_t)d.B * d.ntiles * 8));
-    s.meta_cursor = reinterpret_cast<uint32_t *>(take((size_t)d.B * 4));
+    for (int w = 0; w < 2; ++w) {
+        uint2 *tap_meta = reinterpret_cast<uint2 *>(take(pair_slots * 8));
+        uint32_t *tap_off = reinterpret_cast<uint32_t *>(take((size_t)d.B * d.ntiles * (d.ntap + 1) * 4));
+        uint8_t *tile_flag = reinterpret_cast<uint8_t *>(take((size_t)d.B * d.ntiles));
+        uint4 *tap_split = reinterpret_cast<uint4 *>(take((size_t)d.B * d.ntiles * d.ntap * 16));
+        uint32_t *sched = reinterpret_cast<uint32_t *>(take((size_t)8 * s.sched_cap * 4));
+        uint2 *dsegs = reinterpret_cast<uint2 *>(take((size_t)d.B * d.ntiles * 8));
+        uint32_t *meta_cursor = reinterpret_cast<uint32_t *>(take((size_t)d.B * 4));
+        if (w == which) {
+            s.tap_meta = tap_meta; s.tap_off = tap_off; s.tile_flag = tile_flag; s.tap_split = tap_split;
+            s.sched = sched; s.dsegs = dsegs; s.meta_cursor = meta_cursor;
+        }
+    }
+    // backward only
+    s.pop_mask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * 8));
+    s.tap_cmask = reinterpret_cast<unsigned long long *>(take((size_t)d.B * d.ntiles * d.ntap * 8));
     s.tap_total = reinterpret_cast<uint32_t *>(take(65 * 4));
     s.tap_rng = reinterpret_cast<uint2 *>(take(64 * 8));
     s.items = reinterpret_cast<uint4 *>(take((size_t)(kDwItems + 64) * 16));
+    if (order_bytes) *order_bytes = off;
+    s.wt = reinterpret_cast<float *>(take((size_t)d.ntap * cip * cop * 4));
     s.partials = reinterpret_cast<float *>(take((size_t)(kDwItems + 64) * cip * cop * 4 + nw * 4));
     s.gbuf = reinterpret_cast<float *>(take((size_t)d.B * d.ntiles * d.ntap * 64 * cop * 4));
     s.bytes = off;
     return s;
 }
 
-size_t deep_scratch_bytes(const Dims &d, size_t pair_slots) { return carve_deep(d, pair_slots, nullptr).bytes; }
+size_t deep_scratch_bytes(const Dims &d, size_t pair_slots) { return carve_deep(d, pair_slots, nullptr, 0).bytes; }
+// the part of it the record orders take (the same for every channel shape)
+size_t deep_order_bytes(const Dims &d, size_t pair_slots)
+{
+    size_t b = 0;
+    (void)carve_deep(d, pair_slots, nullptr, 0, &b);
+    return b;
+}
+
+void note_deep_order(const Call<float> &c, int which);
 
 template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratch &ds)
 {
     const Dims &d = c.d;
     if (d.ntap > 64) return CONV3P_ERR_UNSUPPORTED;
+    if (c.order_ok[BWD ? 1 : 0]) return CONV3P_OK;   // built for this geometry by an earlier call, scratch untouched since
     const auto &S = c.L.slot[c.slot];
     const int ng = c.L.ngroups;
     const size_t lds = (size_t)(2 + 4 * kOrderR + 64) * d.ntap * 4 + 256 + (size_t)(2 * 64 * ng + 1 + 8) * 4;
@@ -668,6 +692,7 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
     if (BWD)
         hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.pop_mask, d.ntap, d.B * d.ntiles, kDwItems,
                            ds.items, ds.tap_rng, ds.tap_total + 64);
+    note_deep_order(c, BWD ? 1 : 0);
     return hip_ok();
 }
 
@@ -712,7 +737,9 @@ template <int CI, int CO>
 int deep_forward(const Call<float> &c, const float *input, const float *filter, float *output)
 {
     const Dims &d = c.d;
-    const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials);
+    const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials, 0);
+    for (int w = 0; w < 2; ++w)
+        if (c.order_ok[w]) note_deep_order(c, w);   // this path leaves both orders in place
     TRY(launch_deep_order<false>(c, ds));
     const float *Bm = filter;
     if (d.Cin != CI || d.Cout != CO) {
@@ -730,7 +757,9 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
 {
     const Dims &d = c.d;
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
-    const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials);
+    const DeepScratch ds = carve_deep(d, (size_t)d.B * c.L.pairs_per_cloud, c.L.partials, 1);
+    for (int w = 0; w < 2; ++w)
+        if (c.order_ok[w]) note_deep_order(c, w);   // this path leaves both orders in place
     TRY(launch_deep_order<true>(c, ds));
     TRY(launch_pad_filter(c, filter, CO, CI, 1, ds.wt));
     // dX = sum_f' G_f' . W[f']^T  (K = Cout, N = Cin)
@@ -777,6 +806,10 @@ struct CacheHost {
     uint64_t clock = 0;
     uint64_t gen = 0;                  // bumped by every call that does not carry CONV3P_CACHE_POINTS_UNCHANGED
     uint32_t epoch = 0;
+    // record orders of the matrix-core path left in the scratch region: for which slot, built in which generation
+    // (0: none).  Any call that uses the scratch for something else clears them.
+    int order_slot[2] = {-1, -1};
+    uint64_t order_gen[2] = {0, 0};
     // conv3p_stack_prefetch_*: geometry of `pending_points` enqueued on another stream; ready[l] fires when layer
     // l's lists are complete
     const void *pending_points = nullptr;
@@ -785,6 +818,16 @@ struct CacheHost {
 };
 std::mutex g_cache_mu;
 std::map<void *, CacheHost> g_caches;
+
+void note_deep_order(const Call<float> &c, int which)
+{
+    if (c.cache_key == nullptr) return;   // per-call workspace: nothing outlives the call
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_caches.find(c.cache_key);
+    if (it == g_caches.end()) return;
+    it->second.order_slot[which] = c.slot;
+    it->second.order_gen[which] = c.gen;
+}
 
 // Describes where a call's state lives: a persistent cache or per-call scratch.
 struct Where {
@@ -850,6 +893,13 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     c.evicted_hinted = hinted && h.built_gen[slot] == 0 && c.L.slot[slot].cursor != nullptr;
     c.skip_search = hinted && h.built_gen[slot] == h.gen;
     h.built_gen[slot] = h.gen;
+    c.cache_key = wh.buf;
+    c.gen = h.gen;
+    for (int w = 0; w < 2; ++w)
+        c.order_ok[w] = c.skip_search && c.deep_scratch_ok && h.order_slot[w] == slot && h.order_gen[w] == h.gen && h.gen != 0;
+    // a call with channels may use the scratch region for anything (partials, Z, ...): the orders count as gone unless
+    // the matrix-core path, which leaves them in place, says otherwise (deep_forward / deep_backward re-note them)
+    if (d.Cin > 0) h.order_gen[0] = h.order_gen[1] = 0;
     h.stamp[slot] = ++h.clock;
     h.epoch += 1;
     if (h.epoch == 0) h.epoch = 1;
@@ -928,7 +978,19 @@ int prepare_impl(const T *points, const int32_t *stride, T voxel, int B, int N, 
     TRY(begin_call<T>(c, d, stride, voxel, 0, wh, static_cast<hipStream_t>(stream)));
     TRY(run_prep<T>(points, c));
     TRY(run_cloud_min<T>(points, c));
-    return run_search<T>(c, c.L.slot[c.slot].count, true);
+    TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
+    if constexpr (sizeof(T) == 4) {
+        // CONV3P_CACHE_PREPARE_DEEP_ORDERS: also the matrix-core path's two record orders (forward and backward taps),
+        // so that the layer's calls on these points find them in the scratch region
+        if (wh.persistent && (wh.flags & CONV3P_CACHE_PREPARE_DEEP_ORDERS) != 0) {
+            const size_t pair_slots = (size_t)d.B * c.L.pairs_per_cloud;
+            if (wh.scratch_cap < deep_order_bytes(c.d, pair_slots)) return CONV3P_ERR_WORKSPACE;
+            c.order_ok[0] = c.order_ok[1] = false;
+            TRY(launch_deep_order<false>(c, carve_deep(c.d, pair_slots, c.L.partials, 0)));
+            TRY(launch_deep_order<true>(c, carve_deep(c.d, pair_slots, c.L.partials, 1)));
+        }
+    }
+    return CONV3P_OK;
 }
 
 // geometry of K stencils (same filter extents, K strides) over the same points: one prep, ONE search launch and

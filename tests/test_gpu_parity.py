@@ -578,6 +578,64 @@ def test_deep_channel_path_beyond_one_search_group(dev, N, kind):
     assert rel_err(a[1].cpu().numpy(), dx_ref) <= 1e-5 and rel_err(a[2].cpu().numpy(), dw_ref) <= 5e-5
 
 
+def test_prefetched_record_orders_of_the_matrix_core_path(dev):
+    """conv3p_cache_prepare with CONV3P_CACHE_PREPARE_DEEP_ORDERS leaves the deep path's forward / backward record orders in
+    the cache: the layer's calls on the same points (hinted) skip deep_order_kernel and give bit-identical results; a
+    narrow layer or another stencil in between, or new points, make them rebuild -- results unchanged."""
+    lib = _lib.load()
+    B, N, ci, co = 2, 700, 40, 72
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=1500)
+    P2 = make_case("room", B, N, ci, co, seed=1501)[0]
+    X9 = synth.features(B, N, 9, 1502, points=P)
+    W9 = synth.filter_weights(3, 3, 3, 9, 9, 1503)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tP, tP2, tX, tW, tdY, tX9, tW9 = t(P), t(P2), t(X), t(W), t(dY), t(X9), t(W9)
+    s = (1, 1, 1)
+
+    def orders_run(fn):
+        lib.conv3p_profile_reset()
+        lib.conv3p_profile_enable(1)
+        out = fn()
+        torch.cuda.synchronize()
+        lib.conv3p_profile_enable(0)
+        n = 0
+        for k in range(lib.conv3p_profile_kinds()):
+            if lib.conv3p_profile_name(k).decode() == "deep_order_kernel":
+                c = ctypes.c_uint64(0)
+                lib.conv3p_profile_read(k, ctypes.byref(c), None)
+                n = c.value
+        lib.conv3p_profile_reset()
+        return n, out
+
+    mk = lambda: op.NeighborCache(B, N, torch.float32, dev, slots=2, max_taps=27, max_cin=ci, max_cout=co)
+    ref_cache = mk()
+    y_ref = op.conv3p(tP, tX, tW, s, VOX, cache=ref_cache)
+    dx_ref, dw_ref = op.conv3p_grad(tdY, tP, tX, tW, s, VOX, cache=ref_cache, points_unchanged=True)
+
+    cache = mk()
+    n, _ = orders_run(lambda: op.cache_prepare(tP, (3, 3, 3), s, VOX, cache, deep_orders=True))
+    assert n == 2                                                  # both orders built by the prepare call
+    n, y = orders_run(lambda: op.conv3p(tP, tX, tW, s, VOX, cache=cache, points_unchanged=True))
+    assert n == 0 and torch.equal(y, y_ref)
+    n, (dx, dw) = orders_run(lambda: op.conv3p_grad(tdY, tP, tX, tW, s, VOX, cache=cache, points_unchanged=True))
+    assert n == 0 and torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref)
+    n, y = orders_run(lambda: op.conv3p(tP, tX, tW, s, VOX, cache=cache, points_unchanged=True))   # still in place
+    assert n == 0 and torch.equal(y, y_ref)
+    # a narrow layer uses the scratch region for its own purposes: the orders are rebuilt afterwards
+    op.conv3p_grad(t(synth.upstream_grad(B, N, 9, 1504)), tP, tX9, tW9, s, VOX, cache=cache, points_unchanged=True)
+    n, (dx, dw) = orders_run(lambda: op.conv3p_grad(tdY, tP, tX, tW, s, VOX, cache=cache, points_unchanged=True))
+    assert n == 1 and torch.equal(dx, dx_ref) and torch.equal(dw, dw_ref)
+    # another stencil's wide layer overwrites them too
+    op.cache_prepare(tP, (3, 3, 3), s, VOX, cache, points_unchanged=True, deep_orders=True)
+    op.conv3p(tP, tX, tW, (2, 2, 2), VOX, cache=cache, points_unchanged=True)
+    n, y = orders_run(lambda: op.conv3p(tP, tX, tW, s, VOX, cache=cache, points_unchanged=True))
+    assert n == 1 and torch.equal(y, y_ref)
+    # new points without the hint: everything is rebuilt, results follow the new clouds
+    n, y2 = orders_run(lambda: op.conv3p(tP2, tX, tW, s, VOX, cache=cache))
+    assert n == 1 and rel_err(y2.cpu().numpy(), oracle.forward(P2, X, W, s, VOX, nthreads=8)) <= 1e-5
+    assert rel_err(y_ref.cpu().numpy(), oracle.forward(P, X, W, s, VOX, nthreads=8)) <= 1e-5
+
+
 def test_pair_buffer_overflow_falls_back_correctly(dev):
     """A cache configured with a tiny pair capacity overflows: the small-channel kernels search the tile
     themselves, the deep path hands flagged tiles to the generic kernel.  Results must still be exact."""
