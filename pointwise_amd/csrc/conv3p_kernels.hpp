@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
     auto ld_row = [&](int sl, uint32_t i) {
         const bool ok = i < sg.y && code_fwd(rec[sl].code) != kNoTap;
-        RowLoader<T, CINR>::load(in_cloud + (size_t)(ok ? rec[sl].cand : 0u) * ld.in, xs[sl]);
+        RowLoader<T, CINR>::load(in_cloud + (size_t)(ok ? ((CONV3P_ABLATE & 1024) ? (rec[sl].cand & 63u) : rec[sl].cand) : 0u) * ld.in, xs[sl]);   // (1024: developer, every gather an L1 hit)
     };
     auto start_group = [&](int g) {
         sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
