@@ -318,6 +318,9 @@ def cfg4_report(lib, dev, steps=20, warmup=5):
             "kernel_ms_per_step": {k: round(v[1] / 5, 4) for k, v in kinds.items()}}
 
 
+NB_CFG5 = 3     # distinct batches cycled by the cfg5 legs: odd, so that neither of the two caches ever re-meets its content
+
+
 class GeometryPrefetch:
     """Two neighbour caches used in turn: while a step runs on the current stream, the NEXT batch's geometry (sort +
     search of its clouds) is built in the other cache on a side stream -- what Conv3pStack.prefetch does for the models'
@@ -366,10 +369,12 @@ class GeometryPrefetch:
 
 def cfg5_report(lib, dev, steps=5, warmup=2):
     """cfg5 per-GPU shard: B=16, N=8192 SceneNN-shaped rooms, ONE 128->256 layer, stride 1, forward+backward,
-    geometry rebuilt every step (two alternating batches)."""
+    geometry rebuilt every step (three cycled batches over the two caches)."""
     B, N, ci, co = 16, 8192, 128, 256
     t = lambda a: torch.from_numpy(a).to(dev)
-    Ps = [t(synth.room_like(B, N, 7 + i, extent=(2.4, 2.4, 3.0))) for i in range(2)]
+    # THREE batches over the two alternating caches: a cache never meets the content it already holds (with two, cache k
+    # would always be handed batch k, its hash would match and nothing would be rebuilt -- ADVICE r3)
+    Ps = [t(synth.room_like(B, N, 7 + i, extent=(2.4, 2.4, 3.0))) for i in range(NB_CFG5)]
     X = t(synth.features(B, N, ci, 8, points=Ps[0].cpu().numpy()))
     dY = t(synth.upstream_grad(B, N, co, 9))
     W = t(synth.filter_weights(3, 3, 3, ci, co, 5))
@@ -378,7 +383,7 @@ def cfg5_report(lib, dev, steps=5, warmup=2):
         ctr = [0]
 
         def step():
-            P, Pn = Ps[ctr[0] % 2], Ps[(ctr[0] + 1) % 2]
+            P, Pn = Ps[ctr[0] % NB_CFG5], Ps[(ctr[0] + 1) % NB_CFG5]
             ctr[0] += 1
             cache, hint = geo.cache_for(P)
             op.conv3p(P, X, W, (1, 1, 1), stack.VOXEL, cache=cache, points_unchanged=hint)
@@ -695,7 +700,7 @@ def main_cfg5(args, lib, dev, rank, world):
     forward+backward, then the 884 736-float (3.54 MB) sum all-reduce of grad_filter on the communication stream."""
     B, N, ci, co = 16, 8192, 128, 256
     t = lambda a: torch.from_numpy(a).to(dev)
-    Ps = [t(synth.room_like(B, N, 7 + i + 1000 * rank, extent=(2.4, 2.4, 3.0))) for i in range(2)]
+    Ps = [t(synth.room_like(B, N, 7 + i + 1000 * rank, extent=(2.4, 2.4, 3.0))) for i in range(NB_CFG5)]
     X = t(synth.features(B, N, ci, 8 + 1000 * rank, points=Ps[0].cpu().numpy()))
     dY = t(synth.upstream_grad(B, N, co, 9 + 1000 * rank))
     W = t(synth.filter_weights(3, 3, 3, ci, co, 5))
@@ -708,7 +713,7 @@ def main_cfg5(args, lib, dev, rank, world):
     ctr = [0]
 
     def step():
-        P, Pn = Ps[ctr[0] % 2], Ps[(ctr[0] + 1) % 2]
+        P, Pn = Ps[ctr[0] % NB_CFG5], Ps[(ctr[0] + 1) % NB_CFG5]
         ctr[0] += 1
         cache, hint = geo.cache_for(P)
         op.conv3p(P, X, W, (1, 1, 1), stack.VOXEL, cache=cache, points_unchanged=hint)

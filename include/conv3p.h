@@ -118,7 +118,10 @@ typedef struct conv3p_cache_config {
     int pairs_per_point; /* pair-list capacity per point, averaged over a cloud; 0 = default (256).
                             A cloud that needs more is still handled correctly (slow path).        */
     int max_Cin;         /* largest channel counts of a backward call (sizes the scratch for the   */
-    int max_Cout;        /*   per-workgroup grad_filter partials)                                    */
+    int max_Cout;        /*   per-workgroup grad_filter partials).  Forward calls never need them:  */
+                         /*   a forward whose faster variant wants scratch the cache lacks (the     */
+                         /*   transform + gather forward of 36 -> 13) runs the plain kernel instead, */
+                         /*   same results.  Wide (matrix-core) layers need a cache sized for them. */
     int flags;           /* CONV3P_CACHE_* bits below                                                */
 } conv3p_cache_config;
 
@@ -147,6 +150,12 @@ typedef struct conv3p_cache_config {
 size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_config *cfg);
 /* Drop the host-side bookkeeping of a cache buffer (call before freeing it). */
 int conv3p_cache_forget(void *cache);
+/* Make `cache` (cache_bytes of freshly allocated, possibly RECYCLED device memory) a valid empty cache: zero-fills it on
+ * `stream` and drops any host bookkeeping left for that address.  The "zero-filled once" requirement above, as a call:
+ * a framework allocator (TensorFlow's BFC) can hand back a region that overlaps a cache freed earlier in the step, whose
+ * hashes and slot marks may have survived while its lists were overwritten by temporaries -- content hashes cannot
+ * notice that, zero-filling can (integration/tf_conv3p_shim.cc calls this after every allocate_persistent). */
+int conv3p_cache_init(void *cache, size_t cache_bytes, void *stream);
 
 int conv3p_forward_cached_f32(const float *points, const float *input, const float *filter,
                               const int32_t *stride_xyz, float voxel_size, int B, int N, int Cin,

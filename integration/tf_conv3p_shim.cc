@@ -99,6 +99,8 @@ typedef std::tuple<const void *, int, int, int, int> CacheKey;
 std::mutex g_cache_mu;
 std::map<CacheKey, CacheSlot> g_cache;
 
+void *StreamOf(OpKernelContext *ctx);
+
 // returns the 256-byte aligned cache buffer for this call (allocating or growing it), or nullptr with ctx failed
 char *CacheFor(OpKernelContext *ctx, int elem, int B, int N, int taps, int Cin, int Cout, CacheSlot **slot)
 {
@@ -119,7 +121,8 @@ char *CacheFor(OpKernelContext *ctx, int elem, int B, int N, int taps, int Cin, 
         }
         if (cs.bytes != 0) {
             Tensor *old = cs.tensor.AccessTensor(ctx);
-            (void)conv3p_cache_forget(old->flat<int8>().data());
+            char *op_ = reinterpret_cast<char *>(old->flat<int8>().data());
+            (void)conv3p_cache_forget(op_ + (256 - reinterpret_cast<uintptr_t>(op_) % 256) % 256);   // the address the library saw
         }
         Tensor *fresh = nullptr;
         const Status st = ctx->allocate_persistent(DT_INT8, TensorShape({(int64)need + 256}), &cs.tensor, &fresh);
@@ -128,8 +131,20 @@ char *CacheFor(OpKernelContext *ctx, int elem, int B, int N, int taps, int Cin, 
             ctx->CtxFailureWithWarning(st);
             return nullptr;
         }
-        cs.bytes = need;                     // (uninitialised memory is fine: validity is decided by content hashes
-        cs.cfg = cfg;                        //  on the device, a garbage buffer only costs the rebuild it needs anyway)
+        // The allocator may have recycled a region that overlaps a cache freed earlier (e.g. the one just outgrown):
+        // its hashes and slot marks can survive while its lists were overwritten by temporaries, and the device-side
+        // validation would then trust them.  include/conv3p.h asks for a zero-filled buffer; conv3p_cache_init does it on
+        // the op's stream, ordered before the search that follows.
+        char *raw = reinterpret_cast<char *>(fresh->flat<int8>().data());
+        char *aligned = raw + (256 - reinterpret_cast<uintptr_t>(raw) % 256) % 256;
+        const int rc = conv3p_cache_init(aligned, need, StreamOf(ctx));
+        if (rc != CONV3P_OK) {
+            cs.bytes = 0;
+            ctx->CtxFailure(errors::Internal("Conv3p: cannot initialise the neighbour cache: ", conv3p_status_string(rc)));
+            return nullptr;
+        }
+        cs.bytes = need;
+        cs.cfg = cfg;
     }
     *slot = &cs;
     char *p = reinterpret_cast<char *>(cs.tensor.AccessTensor(ctx)->flat<int8>().data());

@@ -296,9 +296,12 @@ inline bool tap_forward_shape(int elem, int cin, int cout)
 }
 inline size_t tap_forward_bytes(const Dims &d) { return (size_t)d.B * d.N * (size_t)d.ntap * kZRow * 4; }
 
-size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
+// mandatory_only: what the forward cannot run without.  The transform + gather forward's Z array is optional (without
+// it the layer runs on forward_kernel, same results): a persistent cache sized for narrower layers must not be refused
+// for it (Call::tap_scratch_ok decides per call).
+size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint, bool mandatory_only = false)
 {
-    if (tap_forward_shape(elem, d.Cin, d.Cout)) return tap_forward_bytes(d);
+    if (tap_forward_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : tap_forward_bytes(d);
     if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
         return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     return 0;
@@ -936,7 +939,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     c.act = act;
     set_ld(c, ldp, Cin, Cout);
     if (c.strided && !small_shape((int)sizeof(T), Cin, Cout)) return CONV3P_ERR_UNSUPPORTED;   // dense tensors only
-    TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
+    TRY(begin_call<T>(c, d, stride, voxel, forward_scratch_bytes(d, (int)sizeof(T), wh.ppp, wh.persistent), wh, s));
     TRY(run_prep<T>(points, c));
     TRY(run_cloud_min<T>(points, c));
     TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
@@ -1561,6 +1564,17 @@ int conv3p_cache_forget(void *cache)
     if (it != g_caches.end()) {
         for (hipEvent_t e : it->second.ready) (void)hipEventDestroy(e);
         g_caches.erase(it);
+    }
+    return CONV3P_OK;
+}
+
+int conv3p_cache_init(void *cache, size_t cache_bytes, void *stream)
+{
+    if (cache == nullptr) return cache_bytes == 0 ? CONV3P_OK : CONV3P_ERR_INVALID_ARGUMENT;
+    (void)conv3p_cache_forget(cache);
+    if (hipMemsetAsync(cache, 0, cache_bytes, static_cast<hipStream_t>(stream)) != hipSuccess) {
+        (void)hipGetLastError();
+        return CONV3P_ERR_LAUNCH;
     }
     return CONV3P_OK;
 }

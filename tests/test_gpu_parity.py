@@ -502,6 +502,42 @@ def test_cache_garbage_buffer_is_harmless(dev):
     assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
 
 
+def test_forward_only_cache_sized_for_narrow_layers_runs_the_segmentation_head(dev):
+    """max_Cin / max_Cout size the BACKWARD's scratch.  A cache sized for narrow layers must still run the
+    forward of 36 -> 13 (whose faster transform + gather variant wants a Z array the cache lacks): the plain forward
+    kernel takes it, same results as a generously sized cache up to summation order, both the oracle's."""
+    B, N = 2, 512
+    P, X, W, dY = make_case("room", B, N, 36, 13, seed=825)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    small = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=3, max_cout=3)
+    big = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=36, max_cout=13)
+    assert small.nbytes < big.nbytes
+    y_ref = oracle.forward(P, X, W, (1, 1, 1), VOX)
+    for cache in (small, big):
+        y = op.conv3p(t(P), t(X), t(W), (1, 1, 1), VOX, cache=cache)
+        assert rel_err(y.cpu().numpy(), y_ref) <= 1e-5
+    # the backward of that layer does need the scratch: refused loudly, not silently wrong
+    with pytest.raises(op.Conv3pRuntimeError):
+        op.conv3p_grad(t(dY), t(P), t(X), t(W), (1, 1, 1), VOX, cache=small)
+
+
+def test_cache_init_makes_a_recycled_buffer_safe(dev):
+    """conv3p_cache_init (what the TF shim calls after allocate_persistent): a buffer that still holds a VALID cache's
+    control words but whose lists were overwritten -- what a framework allocator can hand back -- is zero-filled on the
+    stream, and the next call rebuilds."""
+    B, N = 2, 256
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=3, max_cout=9)
+    P, X, W, dY = make_case("cube", B, N, 3, 9, seed=821)
+    y0, dx0, dw0 = _both(dev, cache, P, X, W, dY, (1, 1, 1))
+    # overwrite everything behind the first 4 KiB (hashes, versions, slot marks survive; records and lists do not)
+    cache.buf[4096:].random_(0, 255)
+    lib = _lib.load()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    assert lib.conv3p_cache_init(cache.buf.data_ptr(), cache.nbytes, st) == _lib.OK
+    y1, dx1, dw1 = _both(dev, cache, P, X, W, dY, (1, 1, 1))
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+
+
 def test_results_are_bitwise_reproducible(dev):
     """No floating-point atomics on the register-resident paths: two runs give identical bits."""
     P, X, W, dY = make_case("modelnet", 4, 1024, 9, 9, seed=830)

@@ -69,6 +69,8 @@ def test_cache_bytes():
     assert lib.conv3p_cache_bytes(4, 32, 2048, ctypes.byref(_lib.CacheConfig(4, 5000, 0, 9, 9))) == 0
     assert lib.conv3p_cache_bytes(2, 32, 2048, ctypes.byref(cfg)) == 0
     assert lib.conv3p_cache_forget(None) == _lib.OK
+    assert lib.conv3p_cache_init(None, 0, None) == _lib.OK
+    assert lib.conv3p_cache_init(None, 16, None) == _lib.ERR_INVALID_ARGUMENT
 
 
 def test_invalid_arguments_without_touching_the_gpu():
