@@ -516,9 +516,14 @@ def test_forward_only_cache_sized_for_narrow_layers_runs_the_segmentation_head(d
     for cache in (small, big):
         y = op.conv3p(t(P), t(X), t(W), (1, 1, 1), VOX, cache=cache)
         assert rel_err(y.cpu().numpy(), y_ref) <= 1e-5
-    # the backward of that layer does need the scratch: refused loudly, not silently wrong
-    with pytest.raises(op.Conv3pRuntimeError):
-        op.conv3p_grad(t(dY), t(P), t(X), t(W), (1, 1, 1), VOX, cache=small)
+    # the backward's scratch (per-workgroup partials) is mandatory: with a cache too small for it the call is refused
+    # loudly; when the cache's scratch happens to be large enough it must simply be right
+    try:
+        dx, dw = op.conv3p_grad(t(dY), t(P), t(X), t(W), (1, 1, 1), VOX, cache=small)
+    except op.Conv3pRuntimeError:
+        return
+    dx_ref, dw_ref = oracle.backward(dY, P, X, W, (1, 1, 1), VOX)
+    assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
 
 
 def test_cache_init_makes_a_recycled_buffer_safe(dev):
