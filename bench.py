@@ -486,6 +486,8 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if os.environ.get("CONV3P_DEV_MAIN_PRIORITY"):      # developer experiment: the whole bench on a stream of that priority
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["CONV3P_DEV_MAIN_PRIORITY"])))
     lib = _lib.load()
     if args.workload == "cfg5":
         return main_cfg5(args, lib, dev, rank, world)

@@ -158,6 +158,7 @@ inline unsigned grid_of(const BlockMap &m) { return 8u * (unsigned)m.rounds * (u
 // One layout serves both the per-call workspace (1 slot, rebuilt every call) and the persistent
 // neighbour cache (several slots).  Everything a slot holds depends only on (points, stencil).
 constexpr int kGroupTiles = 128;      // candidate tiles per search group (64 KiB of hit masks in LDS)
+constexpr int kFusedMaxPoints = 16384;   // clouds the prep kernel sorts: only their tiles are compact enough for the window tables
 constexpr int kDefaultPairsPerPoint = 256;   // 16-B records; room-like clouds reach ~170 neighbours/point
 
 template <typename T> struct Layout {
@@ -167,6 +168,7 @@ template <typename T> struct Layout {
     PointRec<T> *pts;
     T *boxes;
     T *cmin;   // [B][3] origin of the reference's uniform grid (stencils with an even dilated extent only)
+    unsigned long long *ftab;   // [B][ntiles][kFTableU64] per-tile window tables of the fused search (sorted clouds only)
     // per slot
     struct Slot {
         uint32_t *built_version, *cursor, *ticket;
@@ -211,6 +213,9 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
     L.pts = reinterpret_cast<PointRec<T> *>(take(sizeof(PointRec<T>) * (size_t)B * ntiles * kTile));
     L.boxes = reinterpret_cast<T *>(take(sizeof(T) * (size_t)B * ntiles * 6));
     L.cmin = reinterpret_cast<T *>(take(sizeof(T) * (size_t)B * 3));
+    L.ftab = N <= kFusedMaxPoints
+                 ? reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)B * ntiles * kFTableU64))
+                 : nullptr;
     size_t ppc = (size_t)N * (size_t)pairs_per_point;
     if ((size_t)B * ppc > 0xFFFFFFF0ull) ppc = B ? 0xFFFFFFF0ull / (size_t)B : 0;
     if (ppc > 0x7FFFFFFFull) ppc = 0x7FFFFFFFull;   // headroom for the allocator's transient overshoot (search_tile P2)
@@ -430,12 +435,84 @@ template <typename SlotT> inline const uint32_t *sched_of(const SlotT &S)
 #endif
 }
 
+// ----------------------------------------------------------------------------- fused search (conv3p_search_fused.hpp)
+#ifndef CONV3P_DEV_FUSED_M
+#define CONV3P_DEV_FUSED_M 6     // candidate tiles per wave whose hit masks stay in LDS between the passes
+#endif
+template <typename T> bool fused_ok(const Call<T> &c)
+{
+#ifdef CONV3P_DEV_NO_FUSED_SEARCH   // developer A/B build: the tile-pair pre-filter of search_tile for everything
+    return false;
+#endif
+    const Stencil<T> &st = c.st;
+    if (c.L.ftab == nullptr || st.window) return false;
+    for (int a = 0; a < 3; ++a)
+        if (st.ext[a] > kFMaxExt) return false;
+    return true;
+}
+template <typename T> FusedJob<T> make_fused_job(const Call<T> &c)
+{
+    const auto &S = c.L.slot[c.slot];
+    FusedJob<T> j;
+    j.st = c.st;
+    j.cc = c.cc;
+    j.count = S.count;
+    j.tcount = S.tcount;
+    j.pairs = S.pairs;
+    j.segs = S.segs;
+    j.qsegs = S.qsegs;
+    j.qbm = S.qbm;
+    for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < kFMaxExt; ++k)
+            j.clo[a][k] = (float)(((double)k * c.st.step[a] - (double)c.st.full[a] * 0.5) * (double)kFR);
+    return j;
+}
+// tables of every tile + ONE search launch for `njobs` stencils over the same points + the launch order of the tiles
+template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &jobs, const SchedJobs &sjobs, int njobs)
+{
+    const Dims &d = c.d;
+    const BlockMap bm = make_blockmap(d);
+    int ntap_max = 1, maxfull_max = 1;
+    for (int k = 0; k < njobs; ++k) {
+        ntap_max = std::max(ntap_max, jobs.job[k].st.ntap);
+        maxfull_max = std::max(maxfull_max, jobs.job[k].st.maxfull);
+    }
+    const int mmax = (d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    int M = std::min(mmax, (int)CONV3P_DEV_FUSED_M);
+    while (M > 1 && fused_lds(ntap_max, maxfull_max, (int)sizeof(T), M).total > 40 * 1024) --M;   // large filters: fewer stored masks
+    const size_t lds = fused_lds(ntap_max, maxfull_max, (int)sizeof(T), M).total;
+    if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
+    const float inv16 = (float)((double)kFR / (double)c.st.voxel);
+    Scope sc(K_SEARCH, c.s);
+    hipLaunchKernelGGL(tile_tables_kernel<T>, dim3((d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock, d.B), dim3(256), 0, c.s,
+                       c.L.pts, d.ntiles, inv16, c.L.ftab);
+    bool ext3 = true;
+    for (int k = 0; k < njobs; ++k)
+        for (int a = 0; a < 3; ++a) ext3 &= jobs.job[k].st.ext[a] == 3;
+    auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid_of(bm), njobs), dim3(256), lds, c.s, c.L.pts, c.L.boxes, c.L.ftab, d.N, d.ntiles,
+                           c.L.ngroups, bm, jobs, M, inv16);
+    };
+    if (ext3) launch(search_fused_kernel<T, true>);
+    else launch(search_fused_kernel<T, false>);
+    hipLaunchKernelGGL(tile_sched_kernel, dim3(8, njobs), dim3(1024), 0, c.s, sjobs, d.B, d.ntiles, c.L.ngroups, bm.rounds * d.ntiles);
+    return hip_ok();
+}
+
 template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
     if (c.skip_search && with_pairs) return CONV3P_OK;
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
+    if (with_pairs && count == S.count && fused_ok(c)) {
+        FusedJobs<T> fj;
+        SchedJobs sj;
+        fj.job[0] = make_fused_job(c);
+        sj.job[0] = SchedJob{S.segs, S.sched};
+        return launch_fused<T>(c, fj, sj, 1);
+    }
     const size_t lds = search_lds_bytes(st, c.L.gtiles);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;   // very large filters (> ~340 taps): populations alone exceed LDS
     const BlockMap bm = make_blockmap(d);
@@ -1010,10 +1087,11 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
     if (K > wh.nslots) return CONV3P_ERR_WORKSPACE;     // the stencils would evict each other
     hipStream_t s = static_cast<hipStream_t>(stream);
     SearchJobs<T> jobs;
+    FusedJobs<T> fjobs;
     SchedJobs sjobs;
     int njobs = 0;
     size_t lds = 0;
-    bool any_window = false;
+    bool any_window = false, all_fused = true;
     Call<T> c;
     for (int k = 0; k < K; ++k) {
         TRY(begin_call<T>(c, d, strides + 3 * k, voxel, 0, wh, s));
@@ -1027,6 +1105,8 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         const size_t l = search_lds_bytes(st, c.L.gtiles);
         if (l > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
         lds = l > lds ? l : lds;
+        all_fused &= fused_ok(c);
+        fjobs.job[njobs] = make_fused_job(c);
         SearchJob<T> &j = jobs.job[njobs++];
         j.st = st;
         j.cc = c.cc;
@@ -1039,6 +1119,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         sjobs.job[njobs - 1] = SchedJob{S.segs, S.sched};
     }
     if (njobs == 0) return CONV3P_OK;
+    if (all_fused) return launch_fused<T>(c, fjobs, sjobs, njobs);
 #ifndef CONV3P_DEV_JOBS_IN_ORDER
     // widest stencil first (blockIdx.y ascending is the dispatch order): its boxes meet the most candidate tiles, its
     // workgroups run longest -- started last they would be the launch's tail

@@ -666,6 +666,10 @@ __global__ __launch_bounds__(256) void search_multi_kernel(const PointRec<T> *__
                         j.qbm);
 }
 
+}  // namespace conv3p
+#include "conv3p_search_fused.hpp"
+namespace conv3p {
+
 // ---------------------------------------------------------------------------------
 // tile_sched_kernel: launch order of the query tiles for the kernels that walk the pair lists.  A tile's cost follows
 // the length of its lists, and dense regions of a cloud give tiles of 2-4x the mean (rooms, stride 1: max 18 349 pairs

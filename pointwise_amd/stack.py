@@ -21,7 +21,16 @@ from . import _lib
 from . import conv3p_op as op
 from . import synth
 
+import os
+
 VOXEL = 0.1                       # tf.constant([0.1]), pointcnn2_acsd.py:46
+
+
+def _side_stream(device):
+    """The stream the geometry of the next batch is built on.  CONV3P_DEV_SIDE_PRIORITY (developer experiments only):
+    its HIP priority (lower = more urgent; torch's default is 0)."""
+    pr = os.environ.get("CONV3P_DEV_SIDE_PRIORITY")
+    return torch.cuda.Stream(device=device, priority=int(pr)) if pr else torch.cuda.Stream(device=device)
 CLS_STRIDES = (1, 2, 3, 4)        # pointcnn2_acsd.py:47-65
 HIDDEN = 9
 
@@ -141,7 +150,7 @@ class Conv3pStack:
         cache = self._cache_slot(idx, points)
         main = torch.cuda.current_stream(points.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=points.device)
+            self._side = _side_stream(points.device)
         B, N = points.shape[0], points.shape[1]
         with torch.cuda.device(points.device):
             ok = self._c_call("prefetch", points.data_ptr(), self._real(VOXEL), B, N, cache.buf.data_ptr(), cache.nbytes,
@@ -169,7 +178,7 @@ class Conv3pStack:
         side = None
         if self.overlap_search and idx not in self._pending:
             if self._side is None:
-                self._side = torch.cuda.Stream(device=points.device)
+                self._side = _side_stream(points.device)
             side = self._side.cuda_stream
         fptrs, _ = self._ptr_tables()
         with torch.cuda.device(points.device):
@@ -298,7 +307,7 @@ class Conv3pStack:
         # nothing waits for the first layer's lists here, so all layers' searches go out as ONE launch
         main = torch.cuda.current_stream(points.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=points.device)
+            self._side = _side_stream(points.device)
         self._side.wait_stream(main)                       # `points` is ready on the main stream
         strides = []
         for _, _, s in self.layers:
@@ -313,7 +322,7 @@ class Conv3pStack:
         """All layers' geometry on the side stream; returns one event per layer."""
         main = torch.cuda.current_stream(points.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=points.device)
+            self._side = _side_stream(points.device)
         self._side.wait_stream(main)                       # `points` is ready on the main stream
         events = []
         for li, (_, _, s) in enumerate(self.layers):
