@@ -15,9 +15,10 @@
 //             whatever the stride -- against ~15 per candidate.  Masks stay in LDS (the first few per wave) or are
 //             recomputed.
 //     P2      one reservation for the query tile, centre-major slots (as search_tile)
-//     pass 2  every lane (= centre) pops its hits into its own slots: 4-byte descriptors in the final pair slots
-//     pass 3  dense exact stage (lane = pair, all four waves): the reference's arithmetic decides, exactly as in
-//             search_tile's P3; the descriptor is overwritten by the final PairEntry
+//     pass 2  every wave streams its hits (ranked by ballot into an LDS stream, with the slot each one owns) through the
+//             dense exact stage, lane = pair: the reference's arithmetic decides, exactly as in search_tile's P3 --
+//             except that a pair further than a few ulps from every tap boundary needs no division and its backward tap
+//             is the mirror of the forward one (fused_resolve)
 //   (Several stencils per workgroup -- stage once, look up for all -- was built and measured: 263 us against 203 for
 //   the cfg2 geometry; what the stencils could share is ~8 % of the instructions, what they cost is occupancy.)
 //   Only the exact stage decides; the tables are a superset filter (see the slack analysis at fused_masks).
@@ -38,6 +39,7 @@ constexpr int kFMaxExt = 8;                    // taps per axis the look-up loop
 #ifndef CONV3P_DEV_FUSED_ABLATE
 #define CONV3P_DEV_FUSED_ABLATE 0   // developer timing builds (wrong results): 1 no exact stage, 2 no pass 2, 4 empty masks, 8 no epilogue
 #endif
+constexpr int kFStream = 192;                  // entries of a wave's pair stream (drained 128 at a time, < 64 carried over)
 constexpr int kFMaxE = 12;                     // coarsest table (buckets of 2^12 / 16 voxels); beyond: everything is a candidate
 
 __device__ __forceinline__ int floor_i32(float x)
@@ -143,7 +145,7 @@ template <typename T> struct FusedJobs {
 
 // LDS carve shared by host (size) and device (offsets)
 struct FusedLds {
-    size_t tapmap, cnt, cen, bmk, nqw, misc, red, tab, masks, total;
+    size_t tapmap, cnt, cen, bmk, nqw, misc, red, tab, masks, stream, total;
 };
 __host__ __device__ inline size_t f_a16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ __device__ inline FusedLds fused_lds(int ntap, int maxfull, int elem, int M)
@@ -160,6 +162,7 @@ __host__ __device__ inline FusedLds fused_lds(int ntap, int maxfull, int elem, i
     off = f_a16(off);
     L.tab = off; off += (size_t)kWavesPerBlock * kFTableU64 * 8;
     L.masks = off; off += (size_t)kWavesPerBlock * M * 64 * 8;
+    L.stream = off; off += (size_t)kWavesPerBlock * 2 * kFStream * 4;
     L.total = off;
     return L;
 }
@@ -485,76 +488,79 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
     }
     __syncthreads();
     const bool ok = misc[1] != 0;
-    const uint32_t gbase = misc[0], Ltot = misc[2];
+    const uint32_t gbase = misc[0];
     char *pbase = reinterpret_cast<char *>(job.pairs + gbase);   // this query tile's slots (uniform)
     const T rvoxel = (T)1 / st.voxel;
 
-    // ---- pass 2: every centre pops its hits into its own slots (4-byte descriptor ct << 12 | centre << 6 | candidate
-    //      in the slot's first word; the slot's final content is written by pass 3)
+    // ---- pass 2: every wave turns its masks into a dense stream of (centre, candidate) pairs -- the lanes (= centres)
+    //      pop one hit each per round, ranked by ballot into the wave's LDS stream together with the slot the hit owns
+    //      (centre-major, running per lane) -- and resolves the stream 128 pairs at a time with all lanes busy: the
+    //      reference's arithmetic decides (fused_resolve), one final PairEntry per pre-filter hit (false positives are
+    //      stored as kNoTap entries).  Nothing leaves the wave in between: no barrier, no round trip through memory.
     if (!(CONV3P_DEV_FUSED_ABLATE & 2)) {
+        uint32_t *sdesc = reinterpret_cast<uint32_t *>(smem + L.stream) + wave * (2 * kFStream);
+        uint32_t *sslot = sdesc + kFStream;
         uint32_t off = nqw[wave * 64 + lane] * 8u;   // byte offset of the lane's next slot
-        int ord = 0;
+        int have = 0, ord = 0;
         pf_ct = -1;
-        for_my_tiles([&](int ct, int nxt) {
-            const uint64_t m = ord < M ? masks[(size_t)ord * 64 + lane] : compute_mask(ct, nxt);
-            ++ord;
-            uint64_t mm = m;
-            const uint32_t dbase = ((uint32_t)ct << 12) | ((uint32_t)lane << 6);
-            if (ok) {
-                while (__any(mm != 0)) {
-                    if (mm != 0) {
-                        const uint32_t c = (uint32_t)__builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        *reinterpret_cast<uint32_t *>(pbase + off) = dbase | c;
-                        off += 8u;
-                    }
-                }
-            } else {
-                // pair buffer full: the consumers will search this tile themselves; the populations (and the centres'
-                // backward-tap sets, as search_tile keeps them) are still owed
-                while (__any(mm != 0)) {
-                    if (mm != 0) {
-                        const uint32_t c = (uint32_t)__builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        uint32_t fwd, bwd;
-                        fused_resolve<T>(st, rvoxel, tapmap, cnt, bmk, cen, (uint32_t)lane, cloud_pts[(size_t)ct * kTile + c], true,
-                                         want_bm, want_bm, fwd, bwd);
-                    }
-                }
-            }
-        });
-    }
-    __threadfence_block();
-    __syncthreads();
-
-    // ---- pass 3: dense exact stage, lane = pair; kU chunks of 64 pairs in flight per wave (the descriptor loads, then
-    //      the record gathers, then the arithmetic)
-    if (ok && !(CONV3P_DEV_FUSED_ABLATE & 1)) {
-        constexpr int kU = 2;
-        for (uint32_t s0 = (uint32_t)wave * 64; s0 < Ltot; s0 += 64 * kWavesPerBlock * kU) {
-            uint32_t sl[kU], d[kU];
+        // pairs [first, first + 64 * kU) of the stream, n of them real; kU record gathers in flight per lane
+        auto drain = [&](int n) {
+            if (CONV3P_DEV_FUSED_ABLATE & 1) return;
+            constexpr int kU = 2;
+            uint32_t d[kU], so[kU];
             PointRec<T> v[kU];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                sl[u] = s0 + (uint32_t)(u * 64 * kWavesPerBlock + lane);
-                d[u] = *reinterpret_cast<const uint32_t *>(pbase + (size_t)(sl[u] < Ltot ? sl[u] : Ltot - 1u) * 8u);
+                const int i = u * 64 + lane;
+                d[u] = sdesc[i < n ? i : 0];
+                so[u] = sslot[i < n ? i : 0];
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) v[u] = cloud_pts[(size_t)((d[u] >> 12) * kTile + (d[u] & 63u))];
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                const bool on = sl[u] < Ltot;
+                const bool on = u * 64 + lane < n;
                 const uint32_t ql = (d[u] >> 6) & 63u;
                 uint32_t fwd, bwd;
                 fused_resolve<T>(st, rvoxel, tapmap, cnt, bmk, cen, ql, v[u], on, true, want_bm, fwd, bwd);
-                if (on) {
+                if (on && ok) {   // (pair buffer full: the consumers search this tile themselves; the populations are still owed)
                     PairEntry pe;
                     pe.cand = (uint32_t)v[u].idx;
                     pe.code = pair_code(fwd, bwd, ql);
-                    *reinterpret_cast<PairEntry *>(pbase + (size_t)sl[u] * 8u) = pe;
+                    *reinterpret_cast<PairEntry *>(pbase + so[u]) = pe;
                 }
             }
-        }
+        };
+        for_my_tiles([&](int ct, int nxt) {
+            uint64_t mm = ord < M ? masks[(size_t)ord * 64 + lane] : compute_mask(ct, nxt);
+            ++ord;
+            const uint32_t dbase = ((uint32_t)ct << 12) | ((uint32_t)lane << 6);
+            while (true) {
+                const uint64_t act = __ballot(mm != 0);
+                if (act == 0) break;
+                if (mm != 0) {
+                    const uint32_t c = (uint32_t)__builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const int at = have + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
+                    sdesc[at] = dbase | c;
+                    sslot[at] = off;
+                    off += 8u;
+                }
+                have += __popcll(act);
+                __builtin_amdgcn_wave_barrier();
+                if (have >= 128) {
+                    drain(128);
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t cd = sdesc[128 + lane], cs = sslot[128 + lane];   // (have - 128 <= 63 entries carry over)
+                    __builtin_amdgcn_wave_barrier();
+                    sdesc[lane] = cd;
+                    sslot[lane] = cs;
+                    have -= 128;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        });
+        if (have > 0) drain(have);
     }
     __syncthreads();
 
