@@ -500,6 +500,9 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
     return hip_ok();
 }
 
+// the other stencils a persistent cache holds, as jobs of the same launch (defined with the cache's host record below)
+template <typename T> int add_companions(const Call<T> &c, FusedJobs<T> &fj, SchedJobs &sj, int n);
+
 template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
     if (c.skip_search && with_pairs) return CONV3P_OK;
@@ -511,7 +514,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
         SchedJobs sj;
         fj.job[0] = make_fused_job(c);
         sj.job[0] = SchedJob{S.segs, S.sched};
-        return launch_fused<T>(c, fj, sj, 1);
+        return launch_fused<T>(c, fj, sj, add_companions<T>(c, fj, sj, 1));
     }
     const size_t lds = search_lds_bytes(st, c.L.gtiles);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;   // very large filters (> ~340 taps): populations alone exceed LDS
@@ -883,6 +886,8 @@ struct CacheHost {
     std::vector<unsigned long long> tags;
     std::vector<uint64_t> stamp;
     std::vector<uint64_t> built_gen;   // generation in which the slot's search was last enqueued
+    struct SlotDesc { int fz = 0, fy = 0, fx = 0; int32_t stride[3] = {0, 0, 0}; double voxel = 0.0; };
+    std::vector<SlotDesc> desc;        // what stencil the slot's tag stands for (un-hinted calls rebuild them all together)
     uint64_t clock = 0;
     uint64_t gen = 0;                  // bumped by every call that does not carry CONV3P_CACHE_POINTS_UNCHANGED
     uint32_t epoch = 0;
@@ -956,6 +961,7 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
         h.tags.assign(wh.nslots, 0ull);
         h.stamp.assign(wh.nslots, 0ull);
         h.built_gen.assign(wh.nslots, 0ull);
+        h.desc.assign(wh.nslots, CacheHost::SlotDesc());
     }
     const bool hinted = (wh.flags & CONV3P_CACHE_POINTS_UNCHANGED) != 0 && h.gen != 0;
     if (!hinted) h.gen += 1;
@@ -968,6 +974,12 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
             if (h.stamp[i] < h.stamp[slot]) slot = i;
         h.tags[slot] = tag;
         h.built_gen[slot] = 0;
+    }
+    {
+        CacheHost::SlotDesc &sd = h.desc[slot];
+        sd.fz = d.fz; sd.fy = d.fy; sd.fx = d.fx;
+        sd.stride[0] = stride[0]; sd.stride[1] = stride[1]; sd.stride[2] = stride[2];
+        sd.voxel = (double)voxel;
     }
     c.skip_prep = hinted;
     c.evicted_hinted = hinted && h.built_gen[slot] == 0 && c.L.slot[slot].cursor != nullptr;
@@ -986,6 +998,42 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     c.slot = slot;
     c.cc = make_ctl(c.L, slot, tag, h.epoch, /*force=*/0);
     return CONV3P_OK;
+}
+
+// An un-hinted call on a persistent cache re-validates the points; if they changed, EVERY stencil the cache holds is
+// stale, and the caller (a framework executing a model op by op: 4 strides forward, the same 4 backward) is about to ask
+// for each of them in turn.  The call therefore takes the cache's other stencils along as jobs of its own search launch
+// (one launch for all strides: 115 us instead of 4 x 42 + launch overheads on cfg2); for clouds whose lists are current
+// the extra jobs' workgroups exit at once, as the requested one's do.  Host bookkeeping only: what is rebuilt is still
+// decided on the device.
+template <typename T> int add_companions(const Call<T> &c, FusedJobs<T> &fj, SchedJobs &sj, int n)
+{
+    if (c.cache_key == nullptr || c.skip_prep) return n;   // per-call workspace, or the caller vouches for the points
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_caches.find(c.cache_key);
+    if (it == g_caches.end()) return n;
+    CacheHost &h = it->second;
+    for (int sl = 0; sl < h.nslots && n < kFusedMaxJobs; ++sl) {
+        if (sl == c.slot || h.tags[sl] == 0ull) continue;
+        const CacheHost::SlotDesc &sd = h.desc[sl];
+        if (sd.voxel != (double)c.st.voxel) continue;                 // the window tables are built for ONE voxel size
+        Dims d2 = c.d;
+        d2.fz = sd.fz; d2.fy = sd.fy; d2.fx = sd.fx;
+        d2.ntap = sd.fz * sd.fy * sd.fx;
+        Call<T> c2;
+        c2.d = d2;
+        c2.st = make_stencil<T>(d2, sd.stride, c.st.voxel);
+        c2.L = c.L;
+        c2.slot = sl;
+        c2.s = c.s;
+        c2.cc = make_ctl(c.L, sl, h.tags[sl], c.cc.epoch, /*force=*/0);
+        if (!fused_ok(c2)) continue;
+        fj.job[n] = make_fused_job(c2);
+        sj.job[n] = SchedJob{c.L.slot[sl].segs, c.L.slot[sl].sched};
+        h.built_gen[sl] = h.gen;                                      // a hinted call for it later in this generation skips its search
+        ++n;
+    }
+    return n;
 }
 
 // Stack-level backward: a layer's grad_filter partials stay in the caller's region and are reduced later, together
