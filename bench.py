@@ -124,14 +124,31 @@ SIMDS = 1024
 CLOCK_GHZ = 2.4
 
 
-def valu_issue_fracs(kinds, steps):
-    """Per kernel: fraction of the chip's vector-issue slots its launches use (see the module docstring)."""
-    path = os.path.join(ROOT, "profiles", "valu_latest.json")
+def load_counters(name):
+    """profiles/<name>_latest.json (collected in separate rocprofv3 --pmc passes, tools/collect_profiles.sh) if it was
+    collected for the kernels this run loads: the files carry the sha of the library's sources (`_csrc_sha`,
+    pointwise_amd.build.source_hash()).  Returns (table or None, stale?)."""
+    path = os.path.join(ROOT, "profiles", name + "_latest.json")
     if not os.path.exists(path):
-        return None
+        return None, False
     try:
         table = json.load(open(path))
     except Exception:
+        return None, False
+    from pointwise_amd.build import source_hash
+    try:
+        now = source_hash()
+    except Exception:
+        now = None
+    if table.get("_csrc_sha") != now:
+        return None, True
+    return table, False
+
+
+def valu_issue_fracs(kinds, steps):
+    """Per kernel: fraction of the chip's vector-issue slots its launches use (see the module docstring)."""
+    table, _ = load_counters("valu")
+    if table is None:
         return None
     out = {}
     for k, (n, ms) in kinds.items():
@@ -154,13 +171,24 @@ class Reducer:
         self.stream = torch.cuda.Stream(device=dev) if world > 1 and self.cuda else None
         self.done = None
         self.pairs = []
+        self.waits = []            # (before, after) events on the MAIN stream around its wait for the collective
         self.host_ms = []          # CPU tensors (the gloo tests): the collective is synchronous, timed on the host
         self.timing = False
 
     def wait_previous(self):
-        """Before the buffer is written again (the next backward): the previous step's collective has read it."""
+        """Before the buffer is written again (the next backward): the previous step's collective has read it.
+        In the instrumented pass the wait is bracketed by two events on the main stream: their distance is the time
+        the main stream actually stood still for the collective (allreduce_exposed_ms_per_step)."""
         if self.done is not None:
-            torch.cuda.current_stream(self.dev).wait_event(self.done)
+            main = torch.cuda.current_stream(self.dev)
+            if self.timing:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(main)
+                main.wait_event(self.done)
+                b.record(main)
+                self.waits.append((a, b))
+            else:
+                main.wait_event(self.done)
 
     def launch(self, fused):
         if self.world == 1:
@@ -194,6 +222,21 @@ class Reducer:
         if not self.pairs:
             return None
         return sum(a.elapsed_time(b) for a, b in self.pairs) / steps
+
+    def exposed_ms_per_step(self, steps):
+        """Time the main stream waited for the collective (0 when it hides entirely under the next step's forward)."""
+        if self.host_ms:
+            return sum(self.host_ms) / steps          # synchronous collective: all of it is exposed
+        if not self.waits:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.waits) / steps
+
+
+def rank_spread(local_s, steps, dev):
+    """ms_per_step of the slowest and the fastest rank (the headline uses the slowest, as the contract says)."""
+    lo = -distributed.max_over_ranks(-local_s, dev)
+    hi = distributed.max_over_ranks(local_s, dev)
+    return {"min": round(lo / steps * 1e3, 4), "max": round(hi / steps * 1e3, 4)}
 
 
 # ------------------------------------------------------------------------------------------- CPU legs
@@ -565,8 +608,10 @@ def main():
     t_enqueued = time.perf_counter() - t0       # host side done (diagnostic: is the step host- or GPU-bound?)
     red.finish()
     torch.cuda.synchronize(dev)
+    local_elapsed = time.perf_counter() - t0     # this rank's own clock, before the closing barrier
     distributed.barrier()
     elapsed = distributed.max_over_ranks(time.perf_counter() - t0, dev)
+    spread = rank_spread(local_elapsed, args.steps, dev) if world > 1 else None
 
     # ---- per-kernel HIP-event timing of the same K steps (instrumented, not the timed region) ----
     red.timing = True
@@ -575,6 +620,7 @@ def main():
     torch.cuda.synchronize(dev)
     red.timing = False
     allreduce_ms = red.ms_per_step(args.steps)
+    allreduce_exposed_ms = red.exposed_ms_per_step(args.steps)
     extra = world == 1 and not args.no_extra
     kinds_iso = None
     if extra and prefetch:
@@ -605,10 +651,12 @@ def main():
             avg_s = ms / n * 1e-3
             achieved = bytes_per_launch / avg_s / 1e9
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tpath):
+            ttab, stale_t = load_counters("traffic")
+            _, stale_v = load_counters("valu")
+            counters_stale = stale_t or stale_v
+            if ttab is not None:
                 try:
-                    t = json.load(open(tpath)).get(dom)
+                    t = ttab.get(dom)
                     # measured in separate rocprofv3 --pmc passes (tools/collect_profiles.sh): HBM bytes per launch,
                     # FETCH_SIZE raw + WRITE_SIZE (lower bound; see tools/traffic_json.py for the gfx950 caveat)
                     traffic = t["hbm_bytes_lower"] if isinstance(t, dict) else t
@@ -620,6 +668,9 @@ def main():
                         "avg_launch_us_note": "measured with the headline's side-stream overlap (other kernels share "
                                               "the CUs); achieved/frac use this figure",
                         "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in kinds.items()}}
+            if counters_stale:
+                # the counter files were collected for other kernel sources: traffic / valu_issue_frac are omitted
+                roofline["counters_stale"] = True
             vf = valu_issue_fracs(kinds, args.steps)
             if vf:
                 roofline["valu_issue_frac"] = vf
@@ -654,6 +705,8 @@ def main():
         if world > 1:
             out["rccl_world"] = rccl_world
             out["allreduce_ms_per_step"] = None if allreduce_ms is None else round(allreduce_ms, 4)
+            out["allreduce_exposed_ms_per_step"] = None if allreduce_exposed_ms is None else round(allreduce_exposed_ms, 4)
+            out["ms_per_step_ranks"] = spread
             out["allreduce_bytes"] = int(st.fused_grad.numel() * 4)
         if extra:
             # the drop-in boundary as the TF shim drives it: stateless ops, SELU as separate ops
@@ -736,13 +789,16 @@ def main_cfg5(args, lib, dev, rank, world):
         step()
     red.finish()
     torch.cuda.synchronize(dev)
+    local_elapsed = time.perf_counter() - t0
     distributed.barrier()
     elapsed = distributed.max_over_ranks(time.perf_counter() - t0, dev)
+    spread = rank_spread(local_elapsed, steps, dev) if world > 1 else None
     red.timing = True
     kinds = profile_steps(lib, dev, step, min(steps, 5))
     red.finish()
     torch.cuda.synchronize(dev)
     allreduce_ms = red.ms_per_step(min(steps, 5))
+    allreduce_exposed_ms = red.exposed_ms_per_step(min(steps, 5))
     if rank == 0:
         dt = elapsed / steps
         useful = 3 * 2 * 27 * ci * co * B * N
@@ -764,6 +820,8 @@ def main_cfg5(args, lib, dev, rank, world):
         if world > 1:
             out["rccl_world"] = rccl_world
             out["allreduce_ms_per_step"] = None if allreduce_ms is None else round(allreduce_ms, 4)
+            out["allreduce_exposed_ms_per_step"] = None if allreduce_exposed_ms is None else round(allreduce_exposed_ms, 4)
+            out["ms_per_step_ranks"] = spread
             out["allreduce_bytes"] = int(dW.numel() * 4)
         print(json.dumps(out), flush=True)
     distributed.barrier()

@@ -29,6 +29,18 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
 
 
+def source_hash():
+    """sha256 over the library's sources (csrc/*.hip, *.hpp, include/conv3p.h), 16 hex digits: what the counter files
+    under profiles/ are stamped with, so that bench.py can tell when they were collected for other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in sources()] + [HEADER]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(LIB):
         return True

@@ -183,9 +183,13 @@ def _bench_step_worker(rank, world, port, B, out_dir):
             st.grad_views[li].copy_(torch.from_numpy(dw))
         red.launch(st.fused_grad)
     red.finish()
+    spread = bench.rank_spread(0.010 * (rank + 1), steps, torch.device("cpu"))     # rank r "took" 10 (r + 1) ms
     fields = {"rccl_world": dist.get_world_size(), "allreduce_ms_per_step": red.ms_per_step(steps),
+              "allreduce_exposed_ms_per_step": red.exposed_ms_per_step(steps), "ms_per_step_ranks": spread,
               "allreduce_bytes": int(st.fused_grad.numel() * 8)}
     json.dumps(fields)
+    assert fields["allreduce_exposed_ms_per_step"] == fields["allreduce_ms_per_step"]   # synchronous on CPU tensors
+    assert abs(spread["min"] - 10.0 / steps) < 1e-6 and abs(spread["max"] - 10.0 * world / steps) < 1e-6
     np.save(os.path.join(out_dir, "bench_fused_%d.npy" % rank), st.fused_grad.numpy())
     np.save(os.path.join(out_dir, "bench_fields_%d.npy" % rank),
             np.asarray([fields["rccl_world"], fields["allreduce_ms_per_step"], fields["allreduce_bytes"]], dtype=np.float64))

@@ -5,8 +5,12 @@ rocprofv3 reports both counters in KiB.  MI355X_MICROARCH.md (HBM section): on g
 conv3p kernels mix 16-B record loads with 4-B gathers, so both the raw figure and the doubled-read figure are
 stored: traffic = write + 2*fetch is an UPPER bound, write + fetch a lower bound."""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pointwise_amd.build import source_hash
 
 
 def per_kernel(db, counter):
@@ -18,7 +22,8 @@ def per_kernel(db, counter):
     q = "select %s, avg(value), count(*) from counters_collection where counter_name = ? group by %s" % (ki, ki)
     for name, avg, n in c.execute(q, (counter,)):
         key = name.split("(")[0].replace("void ", "").replace("conv3p::", "").split("<")[0]
-        key = {"backward_sparse_kernel": "backward_kernel"}.get(key, key)   # bench.py's kind: both backward kernels
+        key = {"backward_sparse_kernel": "backward_kernel", "search_fused_kernel": "search_kernel",
+               "search_multi_kernel": "search_kernel"}.get(key, key)   # bench.py's kinds
         a = out.setdefault(key, [0.0, 0])
         a[0] += avg * n
         a[1] += n
@@ -32,4 +37,5 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0) * 1024.0, write.get(k, 0.0) * 1024.0
     res[k] = {"fetch_bytes_raw": round(f), "write_bytes": round(w), "hbm_bytes_lower": round(f + w),
               "hbm_bytes_upper_fetch_x2": round(2 * f + w)}
+res["_csrc_sha"] = source_hash()      # bench.py drops these counters when the library's sources have changed since
 print(json.dumps(res, indent=1))

@@ -2,8 +2,12 @@
 like bench.py's HIP-event kinds (kernel base name without template arguments).
 usage: python tools/valu_json.py <pmc_SQ_WAVES results.db> > profiles/valu_latest.json"""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pointwise_amd.build import source_hash
 
 db = sqlite3.connect(sys.argv[1])
 cur = db.execute("select * from counters_collection limit 1")
@@ -22,6 +26,11 @@ for name, cname, n, avg in db.execute(
     a[1] += n
 # search_multi_kernel runs all strides of a step in one launch: bench.py's "search_kernel" kind times exactly that (the
 # single-stride search_kernel launches of a run are its first step's, before any prefetch)
-if "search_multi_kernel" in acc:
-    acc["search_kernel"] = acc.pop("search_multi_kernel")
-print(json.dumps({k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in sorted(acc.items())}, indent=1))
+# the fused multi-stride search (round 4) likewise; tile_tables_kernel belongs to the same geometry step
+for alias in ("search_fused_kernel", "search_multi_kernel"):
+    if alias in acc:
+        acc["search_kernel"] = acc.pop(alias)
+        break
+out = {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in sorted(acc.items())}
+out["_csrc_sha"] = source_hash()      # bench.py drops these counters when the library's sources have changed since
+print(json.dumps(out, indent=1))
