@@ -49,6 +49,11 @@ python $ROOT/tools/generic_time.py > $OUT/${TAG}_generic_time.txt 2>&1
 # 6. single layers at the cfg4 cloud size (B=16, N=4096 rooms): the models' shapes on the register path, SceneNN's and
 #    other mid-size shapes on the matrix-core path
 for s in "9 9" "36 13" "36 41" "12 9" "16 16" "32 64" "64 64" "64 128"; do python $ROOT/tools/shape_time.py $s 16 4096 room 2>&1 | tail -1; done > $OUT/${TAG}_shape_time.txt
+# 7. (round 4) the geometry alone and the two-stream timeline of the headline: which kernel runs beside which
+( python $ROOT/tools/search_time.py cfg2; python $ROOT/tools/search_time.py cfg4; python $ROOT/tools/search_time.py cfg5 ) 2>/dev/null | grep geometry > $OUT/${TAG}_geometry_time.txt
+$ROOT/tools/headline_timeline.sh 64 > $OUT/${TAG}_headline_timeline.txt 2>&1
+$ROOT/tools/cfg4_timeline.sh > $OUT/${TAG}_cfg4_timeline.txt 2>&1
+python $ROOT/tools/op_boundary.py 2>/dev/null | tail -1 > $OUT/${TAG}_op_boundary.txt
 ./tools/ubench/gather_rate > $OUT/${TAG}_gather_rate.txt 2>&1 || $ROOT/tools/ubench/gather_rate > $OUT/${TAG}_gather_rate.txt 2>&1
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_serial_trace $OUT/${TAG}_pmc_*/ $OUT/${TAG}_deep_trace $OUT/${TAG}_deep_pmc $OUT/${TAG}_deep_pmc_*/   # keep the text summaries, drop the databases
 tail -c 1500 $OUT/${TAG}_bench.json; echo; head -14 $OUT/${TAG}_kernel_stats.txt; cat $OUT/${TAG}_traffic.json
