@@ -564,7 +564,8 @@ def main():
     # whatever --warmup is
     distributed.allreduce_weight_grads(torch.zeros_like(st.fused_grad))
     distributed.barrier()
-    st.tune(tPs[0])                 # set-up: short pair lists on these clouds? -> CONV3P_CACHE_SPARSE_NEIGHBOURHOODS
+    st.tune(tPs[0])                 # set-up: short or long pair lists on these clouds? -> one of the two cache hints
+                                    # (without it the library decides on the device: one empty launch per dilated layer)
     st.prepare(B_PER_GPU, N_POINTS)
     _p = tPs[0][:1, :64].contiguous()
     op.conv3p(_p, _p, st.filters[0], (1, 1, 1), stack.VOXEL)
@@ -700,7 +701,9 @@ def main():
                                       + (", fused RCCL all-reduce of 7290 weight grads" if world > 1 else ""),
                           "global_batch": B_PER_GPU * world, "points_per_cloud": N_POINTS,
                           "parallelism": "dp%d" % world,
-                          "sparse_neighbourhoods_hint": bool(st.sparse_neighbourhoods)},
+                          "backward_kernel_choice": "hint from Conv3pStack.tune() at set-up: " +
+                                                    ("short lists" if st.sparse_neighbourhoods else "long lists")
+                                                    if st.sparse_neighbourhoods is not None else "on the device"},
                "roofline": roofline}
         if world > 1:
             out["rccl_world"] = rccl_world

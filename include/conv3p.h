@@ -131,14 +131,20 @@ typedef struct conv3p_cache_config {
  * launches as well.  Without the flag every call re-validates on the device (always safe).  A wrong promise
  * gives results for the previous clouds. */
 #define CONV3P_CACHE_POINTS_UNCHANGED 1
-/* Tuning hint, valid for the lifetime of the cache: the clouds' neighbourhoods are SPARSE -- on average at most
- * ~30 neighbours per point for the dilated stencils, e.g. surface-sampled objects at N <= 2048 (ModelNet40-shaped
- * clouds have 7-27 at strides 2-4; measured crossover of the two kernels between 27 and 41).  The backward of the dilated narrow layers then keeps its G matrix
- * only for the populated (centre, tap) rows (37 KiB of LDS instead of 79: four workgroups per CU), which pays when
- * the pair lists are short (cfg2: -7 % per step) and costs when they are long (S3DIS-like rooms, ~50 neighbours:
- * +30 % on those kernels).  Results are the reference's either way (same decisions, tolerance of the op); they
- * are NOT bitwise the same with and without the hint (different summation orders). */
-#define CONV3P_CACHE_SPARSE_NEIGHBOURHOODS 2
+/* Which backward kernel serves the dilated narrow layers (9 -> 9 at strides 2-4) depends on the DATA: with short pair
+ * lists (surface-sampled objects at N <= 2048: 7-27 neighbours per point) the one that keeps its G matrix for the
+ * populated (centre, tap) rows only (37 KiB of LDS instead of 79: four workgroups per CU) is faster (cfg2: -7 % per
+ * step); with long ones (S3DIS-like rooms, ~50 neighbours) it is 30 % slower than the dense-G kernel; measured
+ * crossover between 27 and 41.  By DEFAULT the library decides on the device: the search leaves, per stencil, a word
+ * saying whether the lists it just built are short on average (<= 35 pre-filter hits per point over the batch), the
+ * backward launches BOTH kernels and that word lets exactly one of them run -- no host synchronisation, nothing for
+ * the caller to know, one empty launch (~5 us) per such backward call.  A caller who knows its data can save that
+ * launch with one of the two hints below, valid for the lifetime of the cache (Conv3pStack.tune() measures a sample
+ * batch once at set-up and sets one).  Results are the reference's either way (same decisions, tolerance of the op);
+ * the two kernels do not give bitwise the same sums, so runs that must reproduce each other bit for bit should fix the
+ * choice with a hint or keep the data regime well away from the threshold. */
+#define CONV3P_CACHE_SPARSE_NEIGHBOURHOODS 2   /* short lists: the populated-rows kernel alone */
+#define CONV3P_CACHE_DENSE_NEIGHBOURHOODS 8    /* long lists: the dense-G kernel alone */
 /* conv3p_cache_prepare_f32 only: besides the geometry, also build the two record orders (by forward tap, by backward
  * tap) that the matrix-core path of the wide layers (more than 16 channels on either side, fp32) derives from it -- about
  * 7 % of such a layer's forward+backward.  The next forward / backward on the same points in this cache (called with

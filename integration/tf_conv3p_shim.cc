@@ -113,7 +113,8 @@ char *CacheFor(OpKernelContext *ctx, int elem, int B, int N, int taps, int Cin, 
         cfg.pairs_per_point = 0;             // default capacity
         cfg.max_Cin = Cin > cs.cfg.max_Cin ? Cin : cs.cfg.max_Cin;
         cfg.max_Cout = Cout > cs.cfg.max_Cout ? Cout : cs.cfg.max_Cout;
-        cfg.flags = 0;                       // never CONV3P_CACHE_POINTS_UNCHANGED: TF promises nothing between ops
+        cfg.flags = 0;                       // never CONV3P_CACHE_POINTS_UNCHANGED: TF promises nothing between ops; no kernel
+                                             // hint either: the library picks the backward kernel on the device from the lists
         const size_t need = conv3p_cache_bytes(elem, B, N, &cfg);
         if (need == 0) {
             ctx->CtxFailure(errors::InvalidArgument("Conv3p: cannot size the neighbour cache"));

@@ -20,7 +20,8 @@ PASS_FORWARD = 0
 PASS_BACKWARD = 1
 PASS_NEIGHBOR_COUNT = 2
 CACHE_POINTS_UNCHANGED = 1
-CACHE_SPARSE_NEIGHBOURHOODS = 2   # tuning hint, see include/conv3p.h
+CACHE_SPARSE_NEIGHBOURHOODS = 2   # tuning hints, see include/conv3p.h
+CACHE_DENSE_NEIGHBOURHOODS = 8
 CACHE_PREPARE_DEEP_ORDERS = 4     # conv3p_cache_prepare_*: also the matrix-core path's record orders
 ABI_VERSION = 3                # CONV3P_ABI_VERSION of include/conv3p.h
 STACK_MAX_LAYERS = 8

@@ -52,11 +52,12 @@ class NeighborCache:
     is decided on the device by content hash, so reusing it with different clouds is always safe."""
 
     def __init__(self, B, N, dtype, device, slots=5, max_taps=27, pairs_per_point=0, max_cin=36, max_cout=41,
-                 sparse_neighbourhoods=False):
+                 sparse_neighbourhoods=None):
         lib = _lib.load()
         self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout, 0)
-        # CONV3P_CACHE_SPARSE_NEIGHBOURHOODS (include/conv3p.h): tuning hint for clouds with short pair lists
-        self.sparse_neighbourhoods = bool(sparse_neighbourhoods)
+        # None: the library decides on the device which backward kernel serves the dilated narrow layers; True / False:
+        # CONV3P_CACHE_SPARSE_NEIGHBOURHOODS / CONV3P_CACHE_DENSE_NEIGHBOURHOODS (include/conv3p.h), saving an empty launch
+        self.sparse_neighbourhoods = sparse_neighbourhoods
         self.key = (int(B), int(N), dtype, torch.device(device))
         esz = _SFX[dtype][2]
         self.nbytes = lib.conv3p_cache_bytes(esz, B, N, ctypes.byref(self.cfg))
@@ -69,7 +70,8 @@ class NeighborCache:
         holds the same bytes as at the previous cached call (CONV3P_CACHE_POINTS_UNCHANGED); deep_orders (prepare
         only) = CONV3P_CACHE_PREPARE_DEEP_ORDERS."""
         self.cfg.flags = (_lib.CACHE_POINTS_UNCHANGED if points_unchanged else 0) | \
-                         (_lib.CACHE_SPARSE_NEIGHBOURHOODS if self.sparse_neighbourhoods else 0) | \
+                         (0 if self.sparse_neighbourhoods is None else _lib.CACHE_SPARSE_NEIGHBOURHOODS
+                          if self.sparse_neighbourhoods else _lib.CACHE_DENSE_NEIGHBOURHOODS) | \
                          (_lib.CACHE_PREPARE_DEEP_ORDERS if deep_orders else 0)
         return ctypes.addressof(self.cfg)
 

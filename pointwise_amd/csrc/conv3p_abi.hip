@@ -177,6 +177,7 @@ template <typename T> struct Layout {
         uint2 *segs, *qsegs;
         uint32_t *qbm;             // [B][ntiles][64] backward taps each centre's list holds (bit f'; <= 32 taps)
         uint32_t *sched;           // [8][ceil(B / 8) * ntiles] launch order of the tiles per XCD (tile_sched_kernel)
+        uint32_t *regime;          // [1] 1: short pair lists on average (tile_sched_kernel), see SchedJob
         PairEntry *pairs;
     };
     std::vector<Slot> slot;
@@ -235,6 +236,7 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
         S.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups * 64));
         S.qbm = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * ntiles * 64));
         S.sched = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * 8 * (size_t)((B + 7) / 8) * ntiles));
+        S.regime = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t)));
         S.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * (size_t)B * ppc));
     }
     L.partials = reinterpret_cast<T *>(take(scratch_bytes));
@@ -345,6 +347,7 @@ template <typename T> struct Call {
     // backward: grad_input = (dX + addend) * selu'(input)
     bool act = false;
     bool sparse_hint = false;      // CONV3P_CACHE_SPARSE_NEIGHBOURHOODS: short pair lists expected (see conv3p.h)
+    bool dense_hint = false;       // CONV3P_CACHE_DENSE_NEIGHBOURHOODS: long ones (neither: decided on the device)
     bool accum = false;            // backward: add to the grad_input already there (column-split passes)
     const T *addend = nullptr;
     RowLd ld{0, 0, 0, 0, 0};       // row strides of the feature tensors; filled with the dense values by set_ld()
@@ -435,6 +438,15 @@ template <typename SlotT> inline const uint32_t *sched_of(const SlotT &S)
 #endif
 }
 
+// mean pre-filter hits per point below which a slot's lists count as SHORT (populated-rows backward for the dilated narrow
+// layers): Conv3pStack.tune()'s threshold of 32 neighbours per point plus the pre-filter's ~10 % of false positives
+constexpr unsigned long long kShortListsPerPoint = 35;
+template <typename T> SchedJob make_sched_job(const Call<T> &c, int slot)
+{
+    const auto &S = c.L.slot[slot];
+    return SchedJob{S.segs, S.sched, S.cursor, S.regime, kShortListsPerPoint * (unsigned long long)c.d.B * (unsigned long long)c.d.N};
+}
+
 // ----------------------------------------------------------------------------- fused search (conv3p_search_fused.hpp)
 #ifndef CONV3P_DEV_FUSED_M
 #define CONV3P_DEV_FUSED_M 6     // candidate tiles per wave whose hit masks stay in LDS between the passes
@@ -513,7 +525,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
         FusedJobs<T> fj;
         SchedJobs sj;
         fj.job[0] = make_fused_job(c);
-        sj.job[0] = SchedJob{S.segs, S.sched};
+        sj.job[0] = make_sched_job(c, c.slot);
         return launch_fused<T>(c, fj, sj, add_companions<T>(c, fj, sj, 1));
     }
     const size_t lds = search_lds_bytes(st, c.L.gtiles);
@@ -531,7 +543,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
         else launch(search_kernel<T, false>, static_cast<const T *>(nullptr));
         if (with_pairs) {
             SchedJobs sj;
-            sj.job[0] = SchedJob{S.segs, S.sched};
+            sj.job[0] = make_sched_job(c, c.slot);
             hipLaunchKernelGGL(tile_sched_kernel, dim3(8, 1), dim3(1024), 0, c.s, sj, d.B, d.ntiles, c.L.ngroups, bm.rounds * d.ntiles);
         }
     }
@@ -612,13 +624,19 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
     const size_t nw = (size_t)st.ntap * d.Cin * d.Cout;
+    const uint32_t *regime = nullptr;   // non-null: the populated-rows kernel was launched for the short-lists case
 #ifndef CONV3P_DEV_DENSE_BACKWARD   // developer A/B build: always the dense-G kernel
     if constexpr (CI > 0 && CO <= 16 && sizeof(T) == 4) {
         size_t slds = 0;
         // narrow layers: on the caller's hint (short pair lists); layers of >= 16 inputs: always -- their dense G
         // plus the transposed filter take 151 KiB of LDS (one workgroup per CU), the populated rows fit two
-        const bool use = CI >= 16 || c.sparse_hint;
-        const int cap = only_flagged == nullptr && use ? sparse_cap<T>(st, CI, CO, slds) : 0;
+        // layers of >= 16 inputs: always (their dense G plus the transposed filter take 151 KiB of LDS, one workgroup per
+        // CU; the populated rows fit two).  Narrow dilated layers: when the pair lists are short -- on the caller's hint
+        // (CONV3P_CACHE_SPARSE_NEIGHBOURHOODS) this kernel alone; without it BOTH kernels are launched and the slot's
+        // regime word (tile_sched_kernel, from the lists just built) lets exactly one of them run: the choice needs
+        // neither the caller nor a host synchronisation, at the price of one empty launch (~5 us).
+        const int cap = only_flagged == nullptr && !(CI < 16 && c.dense_hint) ? sparse_cap<T>(st, CI, CO, slds) : 0;
+        const bool by_regime = CI < 16 && !c.sparse_hint;
         if (cap > 0) {
             const BlockMap bm = make_blockmap(d);
             Scope sc(K_BACKWARD, c.s);
@@ -627,8 +645,10 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
             hipLaunchKernelGGL((backward_sparse_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), slds, c.s, c.L.pts, c.L.boxes,
                                S.count, S.pairs, S.segs, S.qsegs, S.qbm, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                                bm, grad_input, partials ? partials : c.L.partials, (c.act ? 1 : 0) | (c.accum ? 2 : 0), c.addend,
-                               st.window ? c.L.cmin : nullptr, c.ld, cap, sched_of(S));
-            return hip_ok();
+                               st.window ? c.L.cmin : nullptr, c.ld, cap, sched_of(S),
+                               by_regime ? S.regime : static_cast<const uint32_t *>(nullptr));
+            if (!by_regime) return hip_ok();
+            regime = S.regime;
         }
     }
 #endif
@@ -646,7 +666,7 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
                        S.count, S.pairs, S.segs, S.qsegs, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
                        d.Cin, d.Cout, bm, grad_input, partials ? partials : c.L.partials, only_flagged,
                        ((CI > 0 && c.act) ? 1 : 0) | ((CI > 0 && c.accum) ? 2 : 0), c.addend, gen_slots,
-                       st.window ? c.L.cmin : nullptr, c.ld, sched_of(S));
+                       st.window ? c.L.cmin : nullptr, c.ld, sched_of(S), regime);
     return hip_ok();
 }
 
@@ -932,6 +952,7 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
     c.st = make_stencil<T>(d, stride, voxel);
     c.s = s;
     c.sparse_hint = wh.persistent && (wh.flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS) != 0;
+    c.dense_hint = wh.persistent && !c.sparse_hint && (wh.flags & CONV3P_CACHE_DENSE_NEIGHBOURHOODS) != 0;
     const int ntap_max = wh.persistent ? wh.ntap_max : d.ntap;
     if (d.ntap > ntap_max) return CONV3P_ERR_WORKSPACE;
     if (wh.persistent && scratch > wh.scratch_cap) return CONV3P_ERR_WORKSPACE;
@@ -1029,7 +1050,7 @@ template <typename T> int add_companions(const Call<T> &c, FusedJobs<T> &fj, Sch
         c2.cc = make_ctl(c.L, sl, h.tags[sl], c.cc.epoch, /*force=*/0);
         if (!fused_ok(c2)) continue;
         fj.job[n] = make_fused_job(c2);
-        sj.job[n] = SchedJob{c.L.slot[sl].segs, c.L.slot[sl].sched};
+        sj.job[n] = make_sched_job(c, sl);
         h.built_gen[sl] = h.gen;                                      // a hinted call for it later in this generation skips its search
         ++n;
     }
@@ -1164,7 +1185,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         j.segs = S.segs;
         j.qsegs = S.qsegs;
         j.qbm = S.qbm;
-        sjobs.job[njobs - 1] = SchedJob{S.segs, S.sched};
+        sjobs.job[njobs - 1] = make_sched_job(c, c.slot);
     }
     if (njobs == 0) return CONV3P_OK;
     if (all_fused) return launch_fused<T>(c, fjobs, sjobs, njobs);

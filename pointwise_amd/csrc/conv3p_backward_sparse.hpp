@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
     const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, BlockMap bm, T *__restrict__ grad_input,
     T *__restrict__ partials, int act, const T *__restrict__ addend, const T *__restrict__ cmin, RowLd ld,
     int cap,   // G rows (slots) the LDS allocation holds; >= 64, so every tap fits a round of its own
-    const uint32_t *__restrict__ sched)   // launch order of the tiles (tile_sched_kernel) or nullptr
+    const uint32_t *__restrict__ sched,   // launch order of the tiles (tile_sched_kernel) or nullptr
+    const uint32_t *__restrict__ regime)  // non-null: run only if the slot's lists are SHORT (*regime == 1, tile_sched_kernel);
+                                          // the host then launches backward_kernel too, which runs in the other case
 {
+    if (regime != nullptr && *regime != 1u) return;   // (uniform)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);

@@ -684,6 +684,13 @@ constexpr int kSchedTiles = 4096;
 struct SchedJob {
     const uint2 *segs;
     uint32_t *sched;
+    // The slot's REGIME word: 1 when its pair lists are short on average -- at most `limit` pre-filter hits over the
+    // whole batch (the clouds' allocators: `cursor`) --, else 0.  Which backward kernel is faster depends on it (crossover
+    // between 27 and 41 neighbours per point); computed here, after the search, read by both
+    // backward kernels, so that the choice needs neither the caller nor a host synchronisation.
+    const uint32_t *cursor;
+    uint32_t *regime;
+    unsigned long long limit;
 };
 struct SchedJobs {
     SchedJob job[kMaxJobs];
@@ -693,6 +700,13 @@ __global__ __launch_bounds__(1024) void tile_sched_kernel(SchedJobs jobs, int B,
     __shared__ unsigned long long keys[kSchedTiles];
     const SchedJob &jb = jobs.job[blockIdx.y];
     const int xcd = blockIdx.x;
+    if (xcd == 0 && threadIdx.x < 64 && jb.regime != nullptr) {
+        unsigned long long sum = 0;
+        for (int b = threadIdx.x; b < B; b += 64) sum += jb.cursor[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (threadIdx.x == 0) *jb.regime = sum <= jb.limit ? 1u : 0u;
+    }
     const int nclouds = B > xcd ? (B - xcd + 7) / 8 : 0;
     const int n = nclouds * ntiles;
     uint32_t *out = jb.sched + (size_t)xcd * cap;
@@ -1065,8 +1079,11 @@ __global__ __launch_bounds__(256) void backward_kernel(
     int gen_slots,                           // generic path: number of grad_filter partial slots the workgroups
                                              // spread their atomics over (slot = workgroup % gen_slots)
     const T *__restrict__ cmin,              // per-cloud grid origin (window-mode stencils, overflow path only)
-    RowLd ld, const uint32_t *__restrict__ sched)   // sched: launch order of the tiles (tile_sched_kernel) or nullptr
+    RowLd ld, const uint32_t *__restrict__ sched,   // sched: launch order of the tiles (tile_sched_kernel) or nullptr
+    const uint32_t *__restrict__ regime)            // non-null: run only if the slot's lists are LONG (*regime == 0); the
+                                                    // populated-rows kernel was launched for the other case
 {
+    if (regime != nullptr && *regime != 0u) return;   // (uniform)
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
     const int cout = kSmall ? COUT : cout_rt;

@@ -46,8 +46,10 @@ class Conv3pStack:
         buffer.  Needs use_cache and fuse_selu; shapes outside the register-resident list fall back to the op-by-op
         composition below (same results)."""
         self.use_cache = use_cache
-        # CONV3P_CACHE_SPARSE_NEIGHBOURHOODS for the stack's caches: set by tune() (or by hand before the first batch)
-        self.sparse_neighbourhoods = False
+        # None: the backward kernel of the dilated layers is chosen on the device from the lists themselves; True / False:
+        # the CONV3P_CACHE_SPARSE / DENSE_NEIGHBOURHOODS hint for the stack's caches, set by tune() (or by hand before the
+        # first batch) -- saves one empty launch per dilated layer and step
+        self.sparse_neighbourhoods = None
         self.c_stack = c_stack and use_cache and fuse_selu
         self._inflight = None          # cache index of the batch between forward() and backward()
         self._pending = {}             # cache index -> points tensor whose geometry was prefetched into it
@@ -244,17 +246,19 @@ class Conv3pStack:
         return c
 
     def tune(self, points, threshold=32.0):
-        """Set-up, once per dataset (it synchronises): measure the mean neighbour count of the dilated layers on a
-        sample batch and, when the pair lists are short, give the stack's caches the CONV3P_CACHE_SPARSE_NEIGHBOURHOODS
-        hint of include/conv3p.h (ModelNet40-shaped clouds: 7-27 neighbours -> on; S3DIS-like rooms: 41-55 -> off; measured
-        crossover of the two backward kernels between 27 and 41 neighbours, tools/shape_time.py).
+        """Optional set-up, once per dataset (it synchronises): measure the mean neighbour count of the dilated layers
+        on a sample batch and give the stack's caches the matching hint of include/conv3p.h --
+        CONV3P_CACHE_SPARSE_NEIGHBOURHOODS when the pair lists are short (ModelNet40-shaped clouds: 7-27 neighbours),
+        CONV3P_CACHE_DENSE_NEIGHBOURHOODS when they are long (S3DIS-like rooms: 41-55; measured crossover of the two
+        backward kernels between 27 and 41, tools/shape_time.py).  Without tune() the library takes the same decision
+        on the device from the lists themselves, at the price of one empty kernel launch per dilated layer and step.
         The hint only selects kernels: results stay within the op's tolerance either way."""
         strides = sorted({s for _, _, s in self.layers if s > 1})
         if not strides or not self.use_cache:
-            return False
+            return None
         sample = points[: min(points.shape[0], 8)].contiguous()
         mean = max(float(op.neighbor_count(sample, (3, 3, 3), (s, s, s), VOXEL).sum(dim=2).float().mean()) for s in strides)
-        self.sparse_neighbourhoods = mean <= threshold
+        self.sparse_neighbourhoods = bool(mean <= threshold)
         for c in self._caches:
             if c is not None:
                 c.sparse_neighbourhoods = self.sparse_neighbourhoods

@@ -971,6 +971,29 @@ def test_fp64_register_path_matches_oracle(dev, ci, co, kind, N):
         assert np.array_equal(a, b)
 
 
+# ------------------------------------------------------------------ which backward kernel: decided on the device by default
+@pytest.mark.parametrize("kind,N,expect_sparse", [("modelnet", 2048, True), ("room", 4096, False)])
+def test_backward_kernel_choice_on_the_device_equals_the_matching_hint(dev, kind, N, expect_sparse):
+    """Without a hint both backward kernels of a dilated 9 -> 9 layer are launched and the regime word the search left
+    (short / long pair lists on average) lets exactly one run: the result is bit for bit the hinted kernel's of that
+    regime -- ModelNet-shaped clouds: the populated-rows kernel, rooms: the dense-G kernel -- and the oracle's."""
+    B, s = 2, (2, 2, 2)
+    P, X, W, dY = make_case(kind, B, N, 9, 9, seed=1900 + N)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    res = {}
+    for hint in (None, True, False):
+        cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=9, max_cout=9, sparse_neighbourhoods=hint)
+        res[hint] = op.conv3p_grad(t(dY), t(P), t(X), t(W), s, VOX, cache=cache)
+    same = res[True] if expect_sparse else res[False]
+    other = res[False] if expect_sparse else res[True]
+    assert torch.equal(res[None][0], same[0]) and torch.equal(res[None][1], same[1])
+    assert not torch.equal(res[None][1], other[1])      # (the two kernels sum in different orders)
+    stateless = op.conv3p_grad(t(dY), t(P), t(X), t(W), s, VOX)     # per-call workspace: the same decision
+    assert torch.equal(stateless[0], same[0]) and torch.equal(stateless[1], same[1])
+    dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, VOX)
+    assert rel_err(res[None][0].cpu().numpy(), dx_ref) <= 1e-5 and rel_err(res[None][1].cpu().numpy(), dw_ref) <= 2e-5
+
+
 # ------------------------------------------------------------------ CONV3P_CACHE_SPARSE_NEIGHBOURHOODS (populated-rows backward)
 @pytest.mark.parametrize("kind,B,N,ci,co,s,ppp", [
     ("modelnet", 3, 700, 9, 9, (2, 2, 2), 0), ("modelnet", 2, 2048, 9, 9, (4, 4, 4), 0), ("modelnet", 2, 600, 3, 9, (3, 3, 3), 0),
