@@ -480,7 +480,7 @@ template <typename T> FusedJob<T> make_fused_job(const Call<T> &c)
     return j;
 }
 // tables of every tile + ONE search launch for `njobs` stencils over the same points + the launch order of the tiles
-template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &jobs, const SchedJobs &sjobs, int njobs)
+template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &jobs, const SchedJobs &sjobs, int njobs, bool schedule = true)
 {
     const Dims &d = c.d;
     const BlockMap bm = make_blockmap(d);
@@ -508,7 +508,8 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
     };
     if (ext3) launch(search_fused_kernel<T, true>);
     else launch(search_fused_kernel<T, false>);
-    hipLaunchKernelGGL(tile_sched_kernel, dim3(8, njobs), dim3(1024), 0, c.s, sjobs, d.B, d.ntiles, c.L.ngroups, bm.rounds * d.ntiles);
+    if (schedule)
+        hipLaunchKernelGGL(tile_sched_kernel, dim3(8, njobs), dim3(1024), 0, c.s, sjobs, d.B, d.ntiles, c.L.ngroups, bm.rounds * d.ntiles);
     return hip_ok();
 }
 
@@ -521,11 +522,21 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
-    if (with_pairs && count == S.count && fused_ok(c)) {
+    if (fused_ok(c) && (!with_pairs || count == S.count)) {
         FusedJobs<T> fj;
         SchedJobs sj;
         fj.job[0] = make_fused_job(c);
         sj.job[0] = make_sched_job(c, c.slot);
+        if (!with_pairs) {   // populations only (conv3p_neighbor_count_*): into the caller's tensor, nothing else kept
+            FusedJob<T> &j = fj.job[0];
+            j.count = count;
+            j.tcount = nullptr;
+            j.pairs = nullptr;
+            j.segs = nullptr;
+            j.qsegs = nullptr;
+            j.qbm = nullptr;
+            return launch_fused<T>(c, fj, sj, 1, /*schedule=*/false);
+        }
         return launch_fused<T>(c, fj, sj, add_companions<T>(c, fj, sj, 1));
     }
     const size_t lds = search_lds_bytes(st, c.L.gtiles);

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
     int b, qt;
     if (!block_to_cloud(bm, b, qt)) return;   // uniform for the workgroup
     const FusedJob<T> &job = jobs.job[blockIdx.y];
-    if (slot_valid(job.cc, b)) return;         // this cloud's lists are current (uniform)
+    const bool have_pairs = job.pairs != nullptr;   // nullptr: populations only (the public neighbour-count entry point)
+    if (have_pairs && slot_valid(job.cc, b)) return;   // this cloud's lists are current (uniform)
     const Stencil<T> &st = job.st;
 
     const FusedLds L = fused_lds(st.ntap, st.maxfull, (int)sizeof(T), M);
@@ -465,6 +466,9 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         const uint32_t offq = (uint32_t)wave_excl_scan((int)nq, Ltot);
         const uint32_t cap = job.cc.pairs_per_cloud;
         uint32_t base = 0, ok = 0;
+        if (!have_pairs) {
+            if (lane == 0) misc[0] = misc[1] = misc[2] = 0;
+        } else {
         if (lane == 0) {
             // (see search_tile P2: a reservation that does not fit is taken back at once, the cursor cannot wrap)
             base = Ltot ? atomicAdd(&job.cc.cursor[b], (uint32_t)Ltot) : 0u;
@@ -481,6 +485,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         ok = __shfl(ok, 0);
         job.qsegs[((size_t)b * ntiles + qt) * ngroups * 64 + lane] = ok ? make_uint2(base + offq, nq) : make_uint2(0u, kSegOverflow);
         for (int g = 1; g < ngroups; ++g) job.qsegs[(((size_t)b * ntiles + qt) * ngroups + g) * 64 + lane] = make_uint2(0u, 0u);
+        }
         nqw[lane] = offq;
         nqw[64 + lane] = offq + n0;
         nqw[128 + lane] = offq + n0 + n1;
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
     }
     // commit: the last query tile of the cloud to finish marks the slot's lists as built from the current content
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && have_pairs) {
         const CacheCtl &cc = job.cc;
         const uint32_t t = atomicAdd(&cc.ticket[b], 1u);
         if (t + 1u == (uint32_t)bm.blocks_per_cloud) {

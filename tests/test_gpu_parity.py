@@ -971,6 +971,48 @@ def test_fp64_register_path_matches_oracle(dev, ci, co, kind, N):
         assert np.array_equal(a, b)
 
 
+# ------------------------------------------------------------------ the window-table search at the edges of its tables
+@pytest.mark.parametrize("name,shift,vox,kind,N", [
+    ("far_from_origin", 5000.0, 0.1, "modelnet", 700),      # coordinates of 5e4 voxels: the look-up slack exceeds a bucket -> every point a candidate
+    ("moderately_far", 40.0, 0.1, "modelnet", 700),         # slack of a few hundredths of a bucket: windows stay selective
+    ("tiny_voxel", 0.0, 0.02, "modelnet", 600),             # a tile spans hundreds of buckets: coarsened tables (the oracle's grid refuses much smaller)
+    ("huge_voxel", 0.0, 7.0, "room", 600),                  # the whole cloud in a fraction of a voxel: one bucket per tile
+    ("negative_side", -3.0, 0.1, "room", 900)])
+def test_window_tables_at_extreme_scales(dev, name, shift, vox, kind, N):
+    """conv3p_search_fused.hpp is a superset filter whose fallbacks (coarser buckets for wide tiles, all candidates
+    when fp32 rounding of the coordinates reaches a fraction of a bucket) must never lose a neighbour: populations
+    integer-equal to the oracle's and results within tolerance at coordinate / voxel ratios far from the models'."""
+    B = 2
+    P, X, W, dY = make_case(kind, B, N, 3, 9, seed=2100 + N)
+    P = (P.astype(np.float64) + shift).astype(np.float32)
+    for s in ((1, 1, 1), (3, 3, 3)):
+        ref = (oracle.neighbor_count(P, (3, 3, 3), s, vox), oracle.forward(P, X, W, s, vox)) + oracle.backward(dY, P, X, W, s, vox)
+        check_against(ref, run_hip(dev, P, X, W, dY, s, vox), np.float32)
+
+
+def test_non_finite_points_have_no_neighbours_and_disturb_nobody(dev):
+    """Points with a NaN / Inf coordinate: the tables hold them in no window and give them empty masks as centres (the
+    tile-pair scan's comparisons did the same); every other point's populations are what they are without them."""
+    B, N = 1, 400
+    P, X, W, dY = make_case("modelnet", B, N, 3, 9, seed=2200)
+    bad = np.array([3, 77, 200, 399])
+    P2 = P.copy()
+    P2[0, bad[0], 0] = np.nan
+    P2[0, bad[1], 1] = np.inf
+    P2[0, bad[2], 2] = -np.inf
+    P2[0, bad[3], :] = np.nan
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    s = (2, 2, 2)
+    cnt = op.neighbor_count(t(P2), (3, 3, 3), s, VOX).cpu().numpy()
+    keep = np.setdiff1d(np.arange(N), bad)
+    ref = oracle.neighbor_count(np.ascontiguousarray(P[:, keep]), (3, 3, 3), s, VOX)
+    assert np.array_equal(cnt[0, keep], ref[0])
+    assert not cnt[0, bad].any()
+    y = op.conv3p(t(P2), t(X), t(W), s, VOX).cpu().numpy()
+    y_ref = oracle.forward(np.ascontiguousarray(P[:, keep]), np.ascontiguousarray(X[:, keep]), W, s, VOX)
+    assert rel_err(y[0, keep], y_ref[0]) <= 1e-5 and not y[0, bad].any()
+
+
 # ------------------------------------------------------------------ which backward kernel: decided on the device by default
 @pytest.mark.parametrize("kind,N,expect_sparse", [("modelnet", 2048, True), ("room", 4096, False)])
 def test_backward_kernel_choice_on_the_device_equals_the_matching_hint(dev, kind, N, expect_sparse):
