@@ -2029,12 +2029,20 @@ int conv3p_fc_backward_f32(const float *x, const float *W, const float *y, const
     if ((size_t)2 * dw_steps * (N + 1) * 4 > kMaxLds) return CONV3P_ERR_UNSUPPORTED;   // before anything is launched
     hipLaunchKernelGGL(fc_dz_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, y, dy, M, N, act, dz, db);
     TRY(hip_ok());
+    // waves per workgroup of the two streaming kernels: 32 rows of W per wave, the whole grid in ONE resident round
+    // (two workgroups of ~66 KiB of LDS per CU: 512 slots) -- the model's fc1 (73 728 rows): 5 waves, 461 workgroups
+    auto waves_for = [&](int slots) {
+        const int tiles = (K + 31) / 32;
+        int nw = (tiles + slots - 1) / slots;
+        return nw < 4 ? 4 : (nw > 8 ? 8 : nw);
+    };
     {
         Scope sc(K_FC_DW, s);
         auto launch = [&](auto kern, int steps) {
             const size_t lds = (size_t)2 * steps * (N + 1) * 4;
+            const int nw = waves_for(lds <= 80 * 1024 ? 512 : 256);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((K + 127) / 128)), dim3(256), lds, s, x, dz, M, K, N, dW);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((K + 32 * nw - 1) / (32 * nw))), dim3(64 * nw), lds, s, x, dz, M, K, N, dW);
         };
         if (M <= 32) launch(fc_dw_kernel<16>, 16);
         else if (M <= 64) launch(fc_dw_kernel<32>, 32);
@@ -2044,9 +2052,12 @@ int conv3p_fc_backward_f32(const float *x, const float *W, const float *y, const
     if (dx != nullptr) {
         Scope sc(K_FC_DX, s);
         const int psteps = (N / 8 + 15) / 16 * 16;
-        const size_t lds = (size_t)32 * (8 * psteps + 4) * 4 + (size_t)4 * 32 * 33 * 4;
+        size_t lds = (size_t)32 * (8 * psteps + 4) * 4;                   // the dz tile; the transpose tiles reuse it
+        const int nw = waves_for(lds <= 80 * 1024 ? 512 : 256);
+        if (lds < (size_t)nw * 32 * 33 * 4) lds = (size_t)nw * 32 * 33 * 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fc_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(fc_dx_kernel, dim3((unsigned)((K + 127) / 128), (unsigned)p.mblocks), dim3(256), lds, s, dz, W, M, K, N, dx);
+        hipLaunchKernelGGL(fc_dx_kernel, dim3((unsigned)((K + 32 * nw - 1) / (32 * nw)), (unsigned)p.mblocks), dim3(64 * nw), lds, s, dz, W,
+                           M, K, N, dx);
     }
     return hip_ok();
 }

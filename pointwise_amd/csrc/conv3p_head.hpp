@@ -151,14 +151,17 @@ __global__ __launch_bounds__(256) void fc_dz_kernel(const float *__restrict__ y,
 }
 
 // ---------------------------------------------------------------------------------------------
-// dx[m][k] = sum_n dz[m][n] * W[k][n].  grid = (ceil(K / 128), ceil(M / 32)); wave w owns the 32 rows
-// k = 128 x + 32 w .. +32 of W and computes the transposed block dx^T[k][m]:  A[i = k][kk = n] = W[k][n] comes
+// dx[m][k] = sum_n dz[m][n] * W[k][n].  grid = (ceil(K / (32 nw)), ceil(M / 32)), nw = blockDim.x / 64 waves; wave w owns
+// the 32 rows k = 32 nw x + 32 w .. +32 of W and computes the transposed block dx^T[k][m]:  A[i = k][kk = n] = W[k][n] comes
 // straight from global (lane = one row; 16 bytes per lane and step, each 128-byte line of a row is consumed over 8
 // consecutive steps out of L1, so HBM sees every byte of W once), B[kk = n][j = m] = dz[m][n] from LDS
-// ([32][N + 4], 16-byte reads).  The 32x32 result goes through LDS once more to be stored along k (coalesced).
-// N <= 1024, N % 8 == 0.
+// ([32][N + 4], 16-byte reads).  The 32x32 result goes through LDS once more (the dz tile's space, after a barrier) to be
+// stored along k (coalesced).  N <= 1024, N % 8 == 0.
+// Workgroup size (round 4): the host picks nw so that the whole grid is ONE resident round (66 KiB of LDS: two
+// workgroups per CU, 512 slots; the model's fc1: nw = 5, 461 workgroups -- with four waves and a transpose buffer of
+// its own it was 576 workgroups of 83 KiB, one per CU: three rounds, the last a quarter full; fc_dx 95 -> 84 us, fc_dw 78 -> 59 us).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void fc_dx_kernel(
+__global__ __launch_bounds__(512) void fc_dx_kernel(
     const float *__restrict__ dz, const float *__restrict__ W, int M, int K, int N, float *__restrict__ dx)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,13 +170,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int psteps = (steps + kD - 1) / kD * kD;
     const int ldz = 8 * psteps + 4;
     float *zs = reinterpret_cast<float *>(smem);                       // [32][ldz], zero past column N
-    float *tr = zs + 32 * ldz;                                         // [4 waves][32][33] transpose tiles
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+    float *tr = zs;                                                    // [nw waves][32][33] transpose tiles, AFTER the products
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, nw = (int)blockDim.x >> 6;
     const int m0 = blockIdx.y * 32;
-    for (int m = wave; m < 32; m += 4)
+    for (int m = wave; m < 32; m += nw)
         for (int n = lane; n < 8 * psteps; n += 64) zs[m * ldz + n] = (m0 + m < M && n < N) ? dz[(size_t)(m0 + m) * N + n] : 0.0f;
     __syncthreads();
-    const int kb = blockIdx.x * 128 + wave * 32;
+    const int kb = ((int)blockIdx.x * nw + wave) * 32;
     const int krow = min(kb + (lane & 31), K - 1);                      // clamped: rows past K are computed, not stored
     const float *wrow = W + (size_t)krow * N + 4 * half;                // columns 8 s + 4 half .. + 3
     const float *zrow = zs + (lane & 31) * ldz + 4 * half;
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int u = 0; u < kD; ++u) cur[u] = nxt[u];
     }
     // acc holds dx^T[k = kb + row(r)][m = lane & 31]: transpose through LDS, store rows of dx along k
+    __syncthreads();                                                    // every wave is done with the dz tile
     float *t = tr + wave * 32 * 33;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + (lane & 31)] = acc[r];
@@ -219,23 +223,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
-// dW[k][n] = sum_m x[m][k] * dz[m][n].  grid = ceil(K / 128); wave w owns rows k = 128 x + 32 w .. +32: its x
+// dW[k][n] = sum_m x[m][k] * dz[m][n].  grid = ceil(K / (32 nw)), nw = blockDim.x / 64 waves chosen by the host for one
+// resident round (see fc_dx_kernel); wave w owns rows k = 32 nw x + 32 w .. +32: its x
 // operand (A[i = k][kk = m], one coalesced 128-byte read per batch row) is loaded ONCE into 16 registers and reused
 // for every 32-column block of dz (B from LDS [Mpad][N + 1]).  Every element of dW is written exactly once,
 // 128 contiguous bytes per row and store.  Batches larger than 32 rows add further k-steps (M <= 128).
 // ---------------------------------------------------------------------------------------------
 template <int STEPS>   // MFMA k-steps = batch rows / 2 (16 for the models' 32 clouds per GPU; 32, 64 for larger batches)
-__global__ __launch_bounds__(256) void fc_dw_kernel(const float *__restrict__ x, const float *__restrict__ dz, int M,
+__global__ __launch_bounds__(512) void fc_dw_kernel(const float *__restrict__ x, const float *__restrict__ dz, int M,
                                                     int K, int N, float *__restrict__ dW)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ldz = N + 1;
     float *zs = reinterpret_cast<float *>(smem);                       // [2 STEPS][N + 1], zero rows past M
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
-    for (int m = wave; m < 2 * STEPS; m += 4)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, nw = (int)blockDim.x >> 6;
+    for (int m = wave; m < 2 * STEPS; m += nw)
         for (int n = lane; n < N; n += 64) zs[m * ldz + n] = m < M ? dz[(size_t)m * N + n] : 0.0f;
     __syncthreads();
-    const int kb = blockIdx.x * 128 + wave * 32;
+    const int kb = ((int)blockIdx.x * nw + wave) * 32;
     const int k = min(kb + (lane & 31), K - 1);
     float a[STEPS];
 #pragma unroll
