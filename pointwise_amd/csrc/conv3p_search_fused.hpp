@@ -50,7 +50,7 @@ __device__ __forceinline__ int floor_i32(float x)
 }
 __device__ __forceinline__ bool finite3(float x, float y, float z)
 {
-    return fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) < __builtin_huge_valf();   // (NaN compares false)
+    return (x - x) + (y - y) + (z - z) == 0.0f;   // v - v is 0 for a finite v, NaN for Inf and NaN (no min / max: they drop NaNs)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
