@@ -79,3 +79,26 @@ def test_classification_model_training_step(dev):
     assert rel(hd.dW1.cpu().numpy(), r["dW1"]) <= TOL and rel(hd.dW2.cpu().numpy(), r["dW2"]) <= TOL
     assert rel(dx.cpu().numpy(), carry) <= TOL
     assert rel(fused.cpu().numpy(), np.concatenate([d.reshape(-1) for d in dws])) <= TOL
+
+
+@pytest.mark.gpu
+def test_bench_reducer_device_path_without_a_process_group(dev):
+    """bench.Reducer as the N > 1 legs drive it, on HIP streams (the gloo tests cover CPU tensors only): the collective
+    on its own stream behind the backward, the next backward waiting for it, HIP-event timing of the collective and of
+    the main stream's wait.  No process group here, so the collective itself is a no-op -- stream / event logic only."""
+    import torch
+    import bench
+    red = bench.Reducer(dev, 2)                    # world 2: takes the communication-stream path
+    assert red.stream is not None
+    buf = torch.zeros(7290, device=dev)
+    red.timing = True
+    for step in range(4):
+        red.wait_previous()
+        buf.add_(1.0)                              # "the backward writes the fused buffer"
+        red.launch(buf)
+    red.finish()
+    torch.cuda.synchronize(dev)
+    assert float(buf[0]) == 4.0
+    assert len(red.pairs) == 4 and len(red.waits) == 3
+    assert red.ms_per_step(4) >= 0.0 and red.exposed_ms_per_step(4) >= 0.0
+    assert bench.rank_spread(0.012, 4, dev) == {"min": 3.0, "max": 3.0}
