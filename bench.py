@@ -456,7 +456,10 @@ def cfg5_report(lib, dev, steps=5, warmup=2):
                          "note": "useful (dense-equivalent) flops = 3 x 2*27*Cin*Cout per point; the matrix "
                                  "instructions ISSUED are fewer (only populated (tile, tap) products run) -- see "
                                  "profiles/ for SQ_INSTS_MFMA"},
-            "kernel_ms_per_step": {k: round(v[1] / 2, 4) for k, v in kinds.items()}}
+            "kernel_ms_per_step": {k: round(v[1] / 2, 4) for k, v in kinds.items()},
+            "kernel_ms_per_step_note": "HIP events around each launch in the prefetch leg: prep / search / deep_order run on "
+                                       "the side stream beside the main stream's kernels, so their figures are overlapped "
+                                       "LATENCIES, not kernel cost (alone: profiles/r04_deep_kernel_stats.txt, r04_geometry_time.txt)"}
 
 
 def head_report(lib, dev, steps=20, warmup=3):
@@ -667,7 +670,9 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "avg_launch_us": round(avg_s * 1e6, 2), "bytes_per_launch": int(bytes_per_launch),
                         "avg_launch_us_note": "measured with the headline's side-stream overlap (other kernels share "
-                                              "the CUs); achieved/frac use this figure",
+                                              "the CUs); achieved/frac use this figure; prep / search entries of "
+                                              "kernel_ms_per_step are side-stream latencies under that overlap "
+                                              "(kernel_ms_per_step_isolated: alone)",
                         "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in kinds.items()}}
             if counters_stale:
                 # the counter files were collected for other kernel sources: traffic / valu_issue_frac are omitted
