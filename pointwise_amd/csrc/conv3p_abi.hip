@@ -492,7 +492,11 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
     const int mmax = (d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     int M = std::min(mmax, (int)CONV3P_DEV_FUSED_M);
     while (M > 1 && fused_lds(ntap_max, maxfull_max, (int)sizeof(T), M).total > 40 * 1024) --M;   // large filters: fewer stored masks
+#ifdef CONV3P_DEV_FUSED_LDS_KB   // developer: pad the LDS request (fewer workgroups per CU) to see how the kernel scales with occupancy
+    const size_t lds = std::max(fused_lds(ntap_max, maxfull_max, (int)sizeof(T), M).total, (size_t)CONV3P_DEV_FUSED_LDS_KB * 1024);
+#else
     const size_t lds = fused_lds(ntap_max, maxfull_max, (int)sizeof(T), M).total;
+#endif
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const float inv16 = (float)((double)kFR / (double)c.st.voxel);
     Scope sc(K_SEARCH, c.s);
