@@ -2055,7 +2055,7 @@ int conv3p_fc_backward_f32(const float *x, const float *W, const float *y, const
     TRY(hip_ok());
     if (dx != nullptr) {
         Scope sc(K_FC_DX, s);
-        const int psteps = (N / 8 + 15) / 16 * 16;
+        const int psteps = (N / 8 + 7) / 8 * 8;                            // (fc_dx_kernel's kD)
         size_t lds = (size_t)32 * (8 * psteps + 4) * 4;                   // the dz tile; the transpose tiles reuse it
         const int nw = waves_for(lds <= 80 * 1024 ? 512 : 256);
         if (lds < (size_t)nw * 32 * 33 * 4) lds = (size_t)nw * 32 * 33 * 4;

@@ -159,13 +159,15 @@ __global__ __launch_bounds__(256) void fc_dz_kernel(const float *__restrict__ y,
 // stored along k (coalesced).  N <= 1024, N % 8 == 0.
 // Workgroup size (round 4): the host picks nw so that the whole grid is ONE resident round (66 KiB of LDS: two
 // workgroups per CU, 512 slots; the model's fc1: nw = 5, 461 workgroups -- with four waves and a transpose buffer of
-// its own it was 576 workgroups of 83 KiB, one per CU: three rounds, the last a quarter full; fc_dx 95 -> 84 us, fc_dw 78 -> 59 us).
+// its own it was 576 workgroups of 83 KiB, one per CU: three rounds, the last a quarter full; fc_dx 95 -> 55 us with kD = 8, fc_dw 78 -> 60 us).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void fc_dx_kernel(
     const float *__restrict__ dz, const float *__restrict__ W, int M, int K, int N, float *__restrict__ dx)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kD = 16;
+    // 8 loads in flight per lane, twice: ~130 VGPRs, three waves per SIMD, so that TWO five-wave workgroups share a CU
+    // (with 16 the kernel took 216 VGPRs: two waves per SIMD = one workgroup per CU, i.e. two rounds again)
+    constexpr int kD = 8;
     const int steps = N / 8;                                            // 8 columns per step (4 per half-wave)
     const int psteps = (steps + kD - 1) / kD * kD;
     const int ldz = 8 * psteps + 4;
