@@ -13,6 +13,11 @@ Xs = [torch.from_numpy(synth.features(B, N, cin, 50 + i, points=p.cpu().numpy())
 st = stack.Conv3pStack(cin, ncls, device=dev, seed=3)
 if "--no-tune" not in sys.argv:
     st.tune(Ps[0])
+if "--sparse" in sys.argv:   # developer: the populated-rows backward for the dilated layers whatever the lists look like
+    st.sparse_neighbourhoods = True
+    for c in st._caches:
+        if c is not None:
+            c.sparse_neighbourhoods = True
 ups = [torch.from_numpy(synth.upstream_grad(B, N, ncls, 60)).to(dev)]
 ctr = [0]
 pre = "--no-prefetch" not in sys.argv
