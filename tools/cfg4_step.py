@@ -21,11 +21,14 @@ if "--sparse" in sys.argv:   # developer: the populated-rows backward for the di
 ups = [torch.from_numpy(synth.upstream_grad(B, N, ncls, 60)).to(dev)]
 ctr = [0]
 pre = "--no-prefetch" not in sys.argv
+first = "--prefetch-first" in sys.argv
 def step():
     i = ctr[0] % 3
     ctr[0] += 1
+    if pre and first:
+        st.prefetch(Ps[(i + 1) % 3])      # developer: the next batch's geometry under this batch's FORWARD
     st.forward(Ps[i], Xs[i])
-    if pre:
+    if pre and not first:
         st.prefetch(Ps[(i + 1) % 3])
     st.backward(ups)
 print("cfg4 step: %.4f ms" % (bench.timed(dev, step, 20, 5) * 1e3))
