@@ -1508,7 +1508,7 @@ int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B,
     } else
     for (int l = 0; l < nl; ++l) {
         conv3p_cache_config c2 = *cfg;
-        c2.flags = (l > 0 ? CONV3P_CACHE_POINTS_UNCHANGED : 0) | (cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS);
+        c2.flags = (l > 0 ? CONV3P_CACHE_POINTS_UNCHANGED : 0) | (cfg->flags & (CONV3P_CACHE_SPARSE_NEIGHBOURHOODS | CONV3P_CACHE_DENSE_NEIGHBOURHOODS));
         const Where wh = persistent((int)sizeof(T), B, N, cache, cache_bytes, c2.slots, c2.max_taps, c2.pairs_per_point,
                                     c2.max_Cin, c2.max_Cout, c2.flags);
         TRY(prepare_impl<T>(points, sd->strides[l], voxel, B, N, sd->fz, sd->fy, sd->fx, wh, s));
@@ -1571,7 +1571,7 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
         if (events && !prefetched && hipStreamWaitEvent(main, ev[l], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
         conv3p_cache_config c2 = *cfg;
         c2.flags = ((l > 0 || events) ? CONV3P_CACHE_POINTS_UNCHANGED : 0) |   // the first call of a step re-validates
-                   (cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS);
+                   (cfg->flags & (CONV3P_CACHE_SPARSE_NEIGHBOURHOODS | CONV3P_CACHE_DENSE_NEIGHBOURHOODS));
         const bool head = l == sd->n_hidden;
         const int Cin = head ? CW : (l == 0 ? sd->in_channels : sd->hidden);
         const int Cout = head ? sd->num_class : sd->hidden;
@@ -1657,7 +1657,7 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
     auto where = [&]() {
         return persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
                           cfg->max_Cin, cfg->max_Cout,
-                          CONV3P_CACHE_POINTS_UNCHANGED | (cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS));
+                          CONV3P_CACHE_POINTS_UNCHANGED | (cfg->flags & (CONV3P_CACHE_SPARSE_NEIGHBOURHOODS | CONV3P_CACHE_DENSE_NEIGHBOURHOODS)));
     };
     // external gradient of the concat's column blocks: the caller's, the head's, or their sum
     const T *ext = grad_concat;
