@@ -26,6 +26,7 @@
 #pragma once
 
 #include "conv3p_device.hpp"
+#include <type_traits>
 
 #ifndef CONV3P_ABLATE
 #define CONV3P_ABLATE 0
@@ -563,32 +564,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             const uint32_t len = ti < nne ? rend - rbeg : 0u;
             // (an empty part still issues clamped loads of "its" record 0: point it at the tap's first record, which
             // exists -- the slot after the run's end may never have been written)
-            const uint2 *run = meta + (ti < nne ? toff[f1] + (len != 0 ? rbeg : 0u) : 0u);
+            // Addresses are 32-bit offsets from wave-uniform bases (the tile's records, the cloud's rows: the host
+            // checks N * kreal * 4 < 2^32): one multiply-add per load instead of a 64-bit product.
+            const uint32_t mbase = ti < nne ? toff[f1] + (len != 0 ? rbeg : 0u) : 0u;
+            const uint32_t lenm1 = len != 0 ? len - 1u : 0u;
+            const uint32_t rowb = (uint32_t)kreal * 4u, lbyte = (uint32_t)lstart * 4u;
+            const char *srcb = reinterpret_cast<const char *>(src_cloud);
             constexpr int kU = DEEP_KU, kD = DEEP_KD;
             uint2 m[kD][kU];
             float4 v[kD][kU];
             auto ld_meta = [&](int sl, uint32_t p0) {
 #pragma unroll
-                for (int u = 0; u < kU; ++u) m[sl][u] = run[p0 + u < len ? p0 + u : 0u];
+                for (int u = 0; u < kU; ++u) m[sl][u] = meta[mbase + (p0 + u < lenm1 ? p0 + u : lenm1)];   // (clamped: v_min)
             };
             auto ld_rows = [&](int sl) {
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
-                    const float *row = src_cloud + (size_t)(m[sl][u].x & 0xFFFFFFu) * kreal;
+                    const uint32_t boff = __umul24(m[sl][u].x, rowb);   // (low 24 bits of .x = the neighbour; rowb <= 1024)
                     if constexpr (wide) {
-                        const float4_a4 t = *reinterpret_cast<const float4_a4 *>(row + lstart);
+                        const float4_a4 t = *reinterpret_cast<const float4_a4 *>(srcb + (boff + lbyte));
                         v[sl][u] = make_float4(t.x, t.y, t.z, t.w);
                     } else {                                 // rows of 1..3 floats: clamped scalar loads
+                        const float *row = reinterpret_cast<const float *>(srcb + boff);
                         v[sl][u] = make_float4(row[0], row[kreal > 1 ? 1 : 0], row[kreal > 2 ? 2 : 0], 0.f);
                     }
                 }
             };
             float sum[4] = {0.f, 0.f, 0.f, 0.f};
             uint32_t prev = 64;                              // centre of the running sums (64 = none)
+            // One record.  What bounds this stage is the NUMBER of vector instructions a wave issues per record (two
+            // waves per SIMD: ~9 cycles per instruction; by removal the stage takes the same time whether its rows come
+            // from L1 or from the memory-side cache, and twice as long for 1-KiB rows -- one record per wave instruction
+            // -- as for 512-byte rows -- two): 45 in round 3, ~22 now --
+            //   FULL (kreal == KDIM, the common case): the loaded 16 bytes ARE the lane's four columns, no shifting;
+            //   PRED = false (every lane's step lies inside its run): no select on "inside the run";
+            //   the running sum restarts through its addend (same ? sum : 0), one fma per column;
+            //   non-finite values are no longer looked for here: they reach the accumulators (a non-finite row makes its
+            //   centre's M row non-finite, 1 / population being finite and non-zero; Inf x 0 = NaN in the products),
+            //   where the epilogue finds them -- once per tile instead of once per record.
+            auto rec = [&](auto full_c, auto pred_c, int j, int u, uint32_t p0) {
+                constexpr bool kFull = decltype(full_c)::value, kPred = decltype(pred_c)::value;
+                const bool in = kPred ? p0 + u < len : true;
+                const uint32_t q = m[j][u].x >> 24;
+                const float w = __builtin_bit_cast(float, m[j][u].y);
+                const float4 r = v[j][u];
+                float x[4];
+                if constexpr (kFull) {
+                    x[0] = r.x; x[1] = r.y; x[2] = r.z; x[3] = r.w;
+                } else if constexpr (wide) {
+                    const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        x[c] = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            if (d >= c) x[c] = (shl == d - c) ? rr[d] : x[c];
+                    }
+                } else {
+                    x[0] = col0 + 0 < kreal ? r.x : 0.0f;
+                    x[1] = col0 + 1 < kreal ? r.y : 0.0f;
+                    x[2] = col0 + 2 < kreal ? r.z : 0.0f;
+                    x[3] = 0.0f;
+                }
+                const bool same = q == prev;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {    // (scalars: a select between float4 objects goes through scratch)
+                    const float t = __builtin_fmaf(x[c], w, same ? sum[c] : 0.0f);
+                    sum[c] = kPred ? (in ? t : sum[c]) : t;
+                }
+                prev = kPred ? (in ? q : prev) : q;
+                float *dst = kPred ? (in ? Ag + q * LDA : dummy) : Ag + q * LDA;
+                *reinterpret_cast<float4 *>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            };
             // (control flow is kept WAVE-UNIFORM -- a wave holds several groups with different run lengths, the
             // shorter ones idle on clamped loads and masked stores: with a per-lane loop exit hipcc's wait counts
             // degenerate to draining the queue at the top of every unrolled iteration)
-            if (__any(len != 0)) {
+            auto walk = [&](auto full_c) {
                 ld_meta(0, 0);
                 ld_meta(1, kU);
                 ld_meta(2, 2 * kU);
@@ -607,43 +658,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                         ld_meta((j + 3) % kD, p0 + 3 * kU);
                         ld_rows((j + 2) % kD);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (__all(p0 + kU <= len)) {
 #pragma unroll
-                        for (int u = 0; u < kU; ++u) {
-                            const bool in = p0 + u < len;
-                            const uint32_t q = m[j][u].x >> 24;
-                            const float w = __builtin_bit_cast(float, m[j][u].y);
-                            const float4 r = v[j][u];
-                            // 0 for finite values, NaN otherwise (see the epilogue)
-                            badsum += (r.x - r.x) + (r.y - r.y) + (r.z - r.z) + (r.w - r.w);
-                            float x[4];
-                            if constexpr (wide) {
-                                const float rr[4] = {r.x, r.y, r.z, r.w};
+                            for (int u = 0; u < kU; ++u) rec(full_c, std::false_type{}, j, u, p0);
+                        } else {
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    x[c] = 0.0f;
-#pragma unroll
-                                    for (int d = 0; d < 4; ++d)
-                                        if (d >= c) x[c] = (shl == d - c) ? rr[d] : x[c];
-                                }
-                            } else {
-                                x[0] = col0 + 0 < kreal ? r.x : 0.0f;
-                                x[1] = col0 + 1 < kreal ? r.y : 0.0f;
-                                x[2] = col0 + 2 < kreal ? r.z : 0.0f;
-                                x[3] = 0.0f;
-                            }
-                            const bool same = q == prev;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {    // (scalars: a select between float4 objects goes through scratch)
-                                const float t = same ? __builtin_fmaf(x[c], w, sum[c]) : x[c] * w;
-                                sum[c] = in ? t : sum[c];
-                            }
-                            prev = in ? q : prev;
-                            float *dst = in ? Ag + q * LDA : dummy;
-                            *reinterpret_cast<float4 *>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+                            for (int u = 0; u < kU; ++u) rec(full_c, std::true_type{}, j, u, p0);
                         }
                         p0 += kU;
                     }
                 }
+            };
+            if (__any(len != 0) && !(CONV3P_ABLATE & 131072)) {   // (developer bit: no walk)
+                if (kreal == KDIM) walk(std::true_type{});
+                else walk(std::false_type{});
             }
         }
         __syncthreads();                                     // M of the super-step's taps complete in LDS
@@ -731,6 +759,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
                KDIM, NDIM, (int)BWD, (int)blockIdx.x, wave, wall_clock64() - gstart, gk[0], gk[4], gk[5], nne);
 #endif
     // ---- epilogue: C fragments -> out rows (by original index)
+    // non-finite rows of `src` (or a sum that overflowed) have made some accumulator non-finite: x - x is 0 only for
+    // finite x
+    if (o_on) {
+#pragma unroll
+        for (int i = 0; i < OPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) badsum += acc[i][r] - acc[i][r];
+    }
     const bool bad = __syncthreads_or(!(badsum == 0.0f)) != 0;
     if (bad && threadIdx.x == 0) tile_flag[tile_id] = 1;   // zero rows now, exact accumulation by the generic kernel
     if (o_on) {
