@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
         // grad_input pass: every M_f (= G_f' of this tile) also goes to gbuf, the grad_filter kernel's B operand
         // (only the rows of the centres that have the tap -- the others are zero --, packed in centre order: row r of
         // the stored block is the r-th set bit of tap_cmask; on the SceneNN-shaped rooms 42 % of the rows)
-        if (BWD && gbuf != nullptr) {
+        if (BWD && gbuf != nullptr && !(CONV3P_ABLATE & 262144)) {   // (developer bit: no G store)
             for (int g = 0; g < ntp; ++g) {
                 const float *Af = A + g * 64 * LDA;
                 const uint32_t fg = taps[t0 + g];
