@@ -808,7 +808,8 @@ template <bool BWD> int launch_deep_order(const Call<float> &c, const DeepScratc
                        BWD ? ds.tap_total : nullptr, BWD ? ds.pop_mask : nullptr, ds.tap_split, BWD ? ds.tap_cmask : nullptr);
     hipLaunchKernelGGL(deep_sched_kernel, dim3(8), dim3(1024), 0, c.s, ds.dsegs, d.B, d.ntiles, ds.sched_cap, ds.sched);
     if (BWD)
-        hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), 0, c.s, ds.tap_total, ds.pop_mask, d.ntap, d.B * d.ntiles, kDwItems,
+        hipLaunchKernelGGL(deep_plan_kernel, dim3(1), dim3(1024), (size_t)(d.B * d.ntiles <= kPlanTiles ? d.B * d.ntiles : 0) * 8, c.s,
+                           ds.tap_total, ds.pop_mask, d.ntap, d.B * d.ntiles, kDwItems,
                            ds.items, ds.tap_rng, ds.tap_total + 64);
     note_deep_order(c, BWD ? 1 : 0);
     return hip_ok();

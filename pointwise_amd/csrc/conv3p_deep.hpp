@@ -804,7 +804,7 @@ __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restr
 {
     __shared__ unsigned long long keys[kPlanMax];
     __shared__ uint32_t t1s[kPlanMax];
-    __shared__ uint32_t nf[64], ibeg[65], wtot[2][16];
+    __shared__ uint32_t nf[64], ibeg[65];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid < 64) {
         // n_f = floor share, at least 1, at most one item per tile; the items left over go to the taps with the
@@ -848,19 +848,19 @@ __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restr
     __syncthreads();
     const uint32_t total = ibeg[ntap];                       // <= target + ntap <= kPlanMax (host checks)
     const uint32_t T = (uint32_t)tiles;
-    // populated-tap masks of this thread's contiguous run of `per` tiles: ONE global read for all taps
-    const uint32_t per = (T + 1023u) / 1024u;
-    unsigned long long mask[kPlanTiles / 1024];
-#pragma unroll
-    for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) {
-        const uint32_t t = tid * per + u;
-        const unsigned long long m = pop_mask[T <= (uint32_t)kPlanTiles && u < per && t < T ? t : 0u];
-        mask[u] = T <= (uint32_t)kPlanTiles && u < per && t < T ? m : 0ull;
+    // Every WAVE takes taps wave, wave + 16, ... on its own (no workgroup barrier inside): lane l walks the contiguous
+    // run of `per` tiles [l * per, (l + 1) * per) twice -- once to count the tiles that have the tap (then an exclusive
+    // scan over the lanes), once to write the items that start in its run.  (Round 3: all 1 024 threads on one tap
+    // after the other, a scan through LDS and a barrier per tap: 86 us on the critical path of the in-line cfg5 step.)
+    extern __shared__ unsigned long long pm[];             // [T] the tiles' populated-tap masks (T <= kPlanTiles), read twice per tap
+    if (T <= (uint32_t)kPlanTiles) {
+        for (uint32_t t = tid; t < T; t += 1024) pm[t] = pop_mask[t];
+        __syncthreads();
     }
-    for (int f = 0; f < ntap; ++f) {
+    for (int f = (int)wave; f < ntap; f += 16) {
         const uint32_t n = nf[f], i0 = ibeg[f];
-        if (T > (uint32_t)kPlanTiles) {                      // too many tiles for one run per thread: equal tile ranges
-            for (uint32_t j = tid; j < n; j += 1024) {
+        if (T > (uint32_t)kPlanTiles) {                      // too many tiles for the walk below: equal tile ranges
+            for (uint32_t j = lane; j < n; j += 64) {
                 const uint32_t t0 = (uint32_t)((unsigned long long)j * T / n);
                 keys[i0 + j] = ((unsigned long long)t0 << 32) | ((unsigned long long)f << 16) | j;
                 t1s[i0 + j] = (uint32_t)((unsigned long long)(j + 1) * T / n);
@@ -870,36 +870,37 @@ __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restr
         // work of a tile for this tap = 1 if it is populated (one [Cin x 64].[64 x Cout] product).  Item j of the
         // tap starts at b_j = the first tile whose inclusive work prefix exceeds floor(wall * j / n) (b_0 = 0), i.e.
         // the populated tile with exclusive prefix e starts exactly the items j in
-        // [ceil(e * n / wall), ceil((e + 1) * n / wall)): every thread walks its own tiles with a running prefix and
-        // writes those items -- no prefix array, no search, one barrier per tap.
-        uint32_t mine = 0;
-#pragma unroll
-        for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) mine += (uint32_t)((mask[u] >> f) & 1ull);
-        int wsum;
-        uint32_t excl = (uint32_t)wave_excl_scan((int)mine, wsum);
-        if (lane == 0) wtot[f & 1][wave] = (uint32_t)wsum;
-        __syncthreads();                                     // (wtot is double-buffered: one barrier per tap)
+        // [ceil(e * n / wall), ceil((e + 1) * n / wall)).
+        // Lane l takes the tiles l, l + 64, ...: a row of 64 consecutive masks per LDS read (a contiguous run per lane
+        // put all 64 lanes on one bank: 49 of the kernel's 68 us), the prefix of a tile from the rows' ballots.
+        const uint64_t lt_lane = lane == 0 ? 0ull : (~0ull >> (64 - lane));
         uint32_t wall = 0;
-        for (uint32_t k = 0; k < 16; ++k) {
-            if (k == wave) excl += wall;
-            wall += wtot[f & 1][k];
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            wall += (uint32_t)__popcll(__ballot(t < T && ((pm[t < T ? t : 0u] >> f) & 1ull) != 0));
         }
-        if (tid == 0) {
+        if (lane == 0) {
             keys[i0] = ((unsigned long long)f << 16);        // item 0 starts at the first tile
             t1s[i0 + n - 1] = T;                              // the last item ends at the last tile
         }
-#pragma unroll
-        for (uint32_t u = 0; u < (uint32_t)(kPlanTiles / 1024); ++u) {
-            if (((mask[u] >> f) & 1ull) == 0) continue;
-            const uint32_t t = tid * per + u;
-            const unsigned long long e = excl;
-            excl += 1;
-            uint32_t ja = (uint32_t)((e * n + wall - 1) / wall), jb = (uint32_t)(((e + 1) * n + wall - 1) / wall);
-            if (jb > n) jb = n;
-            for (uint32_t j = ja > 0 ? ja : 1u; j < jb; ++j) {
-                keys[i0 + j] = ((unsigned long long)t << 32) | ((unsigned long long)f << 16) | j;
-                t1s[i0 + j - 1] = t;
+        if (wall == 0) continue;                             // (uniform; a tap no tile has: n items of nothing)
+        uint32_t base = 0;
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const bool has = t < T && ((pm[t < T ? t : 0u] >> f) & 1ull) != 0;
+            const uint64_t m = __ballot(has);
+            if (has) {
+                // (e < tiles <= 8192, n <= 2048: 32-bit products)
+                const uint32_t e = base + (uint32_t)__popcll(m & lt_lane);
+                const uint32_t ja = (e * n + wall - 1u) / wall;
+                uint32_t jb = ((e + 1u) * n + wall - 1u) / wall;
+                if (jb > n) jb = n;
+                for (uint32_t j = ja > 0 ? ja : 1u; j < jb; ++j) {
+                    keys[i0 + j] = ((unsigned long long)t << 32) | ((unsigned long long)f << 16) | j;
+                    t1s[i0 + j - 1] = t;
+                }
             }
+            base += (uint32_t)__popcll(m);
         }
     }
     __syncthreads();
@@ -907,8 +908,20 @@ __global__ __launch_bounds__(1024) void deep_plan_kernel(const uint32_t *__restr
     // keys (every thread reads the same LDS words: broadcasts) -- a bitonic sort spent ~70 barriers here
     for (uint32_t i = tid; i < total; i += 1024) {
         const unsigned long long k = keys[i];
+        // position = number of smaller keys.  The keys of one tap ascend with j (first tiles do), so that number is a
+        // sum of ntap binary searches (~6 steps each) instead of a pass over all `total` keys (1 024 reads per item:
+        // 35 of the kernel's 78 us)
         uint32_t pos = 0;
-        for (uint32_t m = 0; m < total; ++m) pos += keys[m] < k ? 1u : 0u;
+        for (int g = 0; g < ntap; ++g) {
+            const uint32_t base = ibeg[g];
+            uint32_t lo = 0, hi = nf[g];
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (keys[base + mid] < k) lo = mid + 1;
+                else hi = mid;
+            }
+            pos += lo;
+        }
         const uint32_t f = (uint32_t)(k >> 16) & 0xFFFFu, j = (uint32_t)k & 0xFFFFu;
         const uint32_t slot = ibeg[f] + j;
         items[pos] = make_uint4(f, (uint32_t)(k >> 32), t1s[slot], slot);
