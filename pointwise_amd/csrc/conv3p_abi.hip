@@ -821,7 +821,7 @@ int launch_deep_gemm(const Call<float> &c, const float *src, const float *Bm, fl
 {
     const Dims &d = c.d;
     const auto &S = c.L.slot[c.slot];
-    const size_t lds = a16((size_t)(KD < 256 ? 256 / KD : 1) * 64 * (KD + 4) * 4) + 68 * 4 + 256 + 4096;
+    const size_t lds = a16((size_t)(KD < 256 ? 256 / KD : 1) * 64 * (KD + 4) * 4) + 68 * 4 + 256 + 4096 + 512;
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     if ((size_t)d.N * (size_t)kreal * 4 > 0xFFFFFFFFull) return CONV3P_ERR_UNSUPPORTED;   // (stage 1 addresses rows by 32-bit offsets)
     const BlockMap bm = make_blockmap(d);
