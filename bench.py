@@ -582,8 +582,10 @@ def main():
         def step():
             i = counter[0] % NBATCH
             counter[0] += 1
+            if pre and os.environ.get("CONV3P_DEV_PREFETCH_FIRST") == "1":   # developer A/B: geometry under the forward
+                stk.prefetch(tPs[(i + 1) % NBATCH])
             stk.forward(tPs[i], tXs[i])
-            if pre:
+            if pre and os.environ.get("CONV3P_DEV_PREFETCH_FIRST") != "1":
                 # the next batch's geometry (1 sort + 4 searches) goes to the side stream now and runs under this
                 # batch's backward, as a data-loader-fed training loop would do.  Every step still performs exactly
                 # one full geometry build, one forward and one backward inside the timed region.
