@@ -279,11 +279,30 @@ inline int generic_slots(const Dims &d, int elem)
     return s < 1 ? 1 : (int)s;
 }
 
+// fp32 layers with more than 256 channels on a side (round 4): column blocks of at most 256 x 256 channels on the
+// matrix-core kernels -- the op is linear in the input-channel blocks and independent over the output-channel blocks
+// -- instead of the global-atomics kernels.  Scratch: the matrix-core path's own for a 256 x 256 block, then packed
+// copies of the block's rows (input / grad_out / result: 3 x [B N][256]) and of its filter block and grad_filter block.
+constexpr int kWideBlk = 256;
+inline bool wide_shape(int elem, int cin, int cout)
+{
+    return elem == 4 && cin >= 1 && cout >= 1 && (cin > kWideBlk || cout > kWideBlk);
+}
+inline size_t wide_scratch_bytes(const Dims &d, size_t pair_slots)
+{
+    Dims db = d;
+    db.Cin = kWideBlk;    // (blocks are padded to 128 or 256 channels: sized for the largest)
+    db.Cout = kWideBlk;
+    const size_t rows = (size_t)d.B * d.N;
+    return up(deep_scratch_bytes(db, pair_slots)) + 3 * up(rows * kWideBlk * 4) + 2 * up((size_t)d.ntap * kWideBlk * kWideBlk * 4);
+}
+
 // ppp: pair slots per point of the buffer the call runs in (a cache may be configured with fewer than the default)
 size_t backward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
 {
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
     size_t deep = 0;
+    if (wide_shape(elem, d.Cin, d.Cout)) deep = wide_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
         deep = deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     // register path: one partial per workgroup; generic path (also the fallback of the other two): generic_slots
@@ -311,6 +330,7 @@ size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPer
     if (tap_forward_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : tap_forward_bytes(d);
     if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
         return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+    if (wide_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : wide_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     return 0;
 }
 
@@ -337,6 +357,7 @@ template <typename T> struct Call {
     hipStream_t s;
     bool deep_scratch_ok = false;  // the scratch region can hold the deep path's side arrays
     bool tap_scratch_ok = false;   // ... the transform + gather forward's Z array
+    bool wide_scratch_ok = false;  // ... the blocked path of layers with more than 256 channels
     bool order_ok[2] = {false, false};   // the deep path's forward / backward record order of this geometry is in the scratch
     void *cache_key = nullptr;     // persistent cache the call runs in (host bookkeeping of the record orders)
     uint64_t gen = 0;
@@ -908,6 +929,130 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
     return hip_ok();
 }
 
+// ----------------------------------------------------------------------------- layers of more than 256 channels
+// A block of kw <= 256 channels is packed into rows of 128 or 256 floats, zero-filled past kw: every block then IS one of
+// the instantiated shapes {128, 256}^2 with full rows (the kernels' fast path), whatever the layer's channel counts.
+inline int wide_pad(int n) { return n <= 128 ? 128 : 256; }
+struct WideScratch {
+    float *xp, *yp, *zp;   // [B N][256] packed rows: block input, block grad_out (backward), block result
+    float *wp, *dwp;       // [ntap][256][256] packed filter block, its grad_filter block
+};
+inline WideScratch carve_wide(const Call<float> &c)
+{
+    const Dims &d = c.d;
+    Dims db = d;
+    db.Cin = kWideBlk;
+    db.Cout = kWideBlk;
+    const size_t rows = (size_t)d.B * d.N;
+    char *p = reinterpret_cast<char *>(c.L.partials) + up(deep_scratch_bytes(db, (size_t)d.B * c.L.pairs_per_cloud));
+    WideScratch w{};
+    w.xp = reinterpret_cast<float *>(p); p += up(rows * kWideBlk * 4);
+    w.yp = reinterpret_cast<float *>(p); p += up(rows * kWideBlk * 4);
+    w.zp = reinterpret_cast<float *>(p); p += up(rows * kWideBlk * 4);
+    w.wp = reinterpret_cast<float *>(p); p += up((size_t)d.ntap * kWideBlk * kWideBlk * 4);
+    w.dwp = reinterpret_cast<float *>(p);
+    return w;
+}
+inline unsigned grid_1d(size_t n) { return (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+// dst [rows][ldp] = src[:, 0 .. cols) zero-filled to ldp columns
+inline int wide_pack_rows(const Call<float> &c, const float *src, int ld_s, float *dst, size_t rows, int cols, int ldp)
+{
+    if (cols < ldp) TRY(zero_async(dst, rows * (size_t)ldp * 4, c.s));
+    hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(grid_1d(rows * cols)), dim3(256), 0, c.s, src, dst, rows, cols, ld_s, ldp);
+    return CONV3P_OK;
+}
+// wp [ntap][kwp][cwp] = filter[:, k0 .. k0 + kw, c0 .. c0 + cw) zero-filled
+inline int wide_pack_filter(const Call<float> &c, const float *filter, int k0, int kw, int c0, int cw, int kwp, int cwp, float *wp)
+{
+    const Dims &d = c.d;
+    if (kw < kwp || cw < cwp) TRY(zero_async(wp, (size_t)d.ntap * kwp * cwp * 4, c.s));
+    hipLaunchKernelGGL(copy_block_kernel<float>, dim3(grid_1d((size_t)d.ntap * kw * cw)), dim3(256), 0, c.s,
+                       filter + (size_t)k0 * d.Cout + c0, wp, d.ntap, kw, cw, (size_t)d.Cin * d.Cout, d.Cout, (size_t)kwp * cwp, cwp);
+    return CONV3P_OK;
+}
+
+// out[:, c0 .. c0 + cw) = sum over the input-channel blocks of conv(input[:, k0 .. k0 + kw), filter[:, k-block, c-block]):
+// every block runs on the matrix-core kernels from packed copies (the same geometry and record order for all of them),
+// the blocks' results are added in ascending k0 -- deterministic.
+int wide_forward(const Call<float> &c, const float *input, const float *filter, float *output)
+{
+    const Dims &d = c.d;
+    const size_t rows = (size_t)d.B * d.N;
+    const WideScratch w = carve_wide(c);
+    bool have_order = c.order_ok[0];
+    for (int c0 = 0; c0 < d.Cout; c0 += kWideBlk) {
+        const int cw = d.Cout - c0 < kWideBlk ? d.Cout - c0 : kWideBlk, cwp = wide_pad(cw);
+        for (int k0 = 0; k0 < d.Cin; k0 += kWideBlk) {
+            const int kw = d.Cin - k0 < kWideBlk ? d.Cin - k0 : kWideBlk, kwp = wide_pad(kw);
+            TRY(wide_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kwp));
+            TRY(wide_pack_filter(c, filter, k0, kw, c0, cw, kwp, cwp, w.wp));
+            Call<float> cp = c;
+            cp.d.Cin = kwp;
+            cp.d.Cout = cwp;
+            cp.act = false;
+            cp.order_ok[0] = have_order;
+            set_ld(cp, nullptr, kwp, cwp);
+            int rc = CONV3P_ERR_UNSUPPORTED;
+#define X(ci, co) if (kwp == ci && cwp == co) rc = deep_forward<ci, co>(cp, w.xp, w.wp, w.zp);
+            CONV3P_DEEP_SHAPES(X)
+#undef X
+            if (rc != CONV3P_OK) return rc;
+            have_order = true;
+            if (k0 == 0)
+                hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(grid_1d(rows * cw)), dim3(256), 0, c.s, w.zp, output + c0, rows, cw,
+                                   cwp, d.Cout);
+            else
+                hipLaunchKernelGGL(add_cols_kernel<float>, dim3(grid_1d(rows * cw)), dim3(256), 0, c.s, w.zp, output + c0, rows, cw,
+                                   cwp, d.Cout);
+        }
+    }
+    return hip_ok();
+}
+
+// grad_input[:, k-block] = sum over the output-channel blocks (ascending c0) of the block's grad_input; every
+// (k-block, c-block) pair gives its own block of grad_filter.
+int wide_backward(const Call<float> &c, const float *grad_out, const float *input, const float *filter, float *grad_input,
+                  float *grad_filter)
+{
+    const Dims &d = c.d;
+    const size_t rows = (size_t)d.B * d.N;
+    const WideScratch w = carve_wide(c);
+    bool have_order = c.order_ok[1];
+    for (int k0 = 0; k0 < d.Cin; k0 += kWideBlk) {
+        const int kw = d.Cin - k0 < kWideBlk ? d.Cin - k0 : kWideBlk, kwp = wide_pad(kw);
+        TRY(wide_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kwp));
+        for (int c0 = 0; c0 < d.Cout; c0 += kWideBlk) {
+            const int cw = d.Cout - c0 < kWideBlk ? d.Cout - c0 : kWideBlk, cwp = wide_pad(cw);
+            TRY(wide_pack_rows(c, grad_out + c0, d.Cout, w.yp, rows, cw, cwp));
+            TRY(wide_pack_filter(c, filter, k0, kw, c0, cw, kwp, cwp, w.wp));
+            Call<float> cp = c;
+            cp.d.Cin = kwp;
+            cp.d.Cout = cwp;
+            cp.act = false;
+            cp.accum = false;
+            cp.addend = nullptr;
+            cp.order_ok[1] = have_order;
+            set_ld(cp, nullptr, kwp, cwp);
+            int rc = CONV3P_ERR_UNSUPPORTED;
+#define X(ci, co) if (kwp == ci && cwp == co) rc = deep_backward<ci, co>(cp, w.yp, w.xp, w.wp, w.zp, w.dwp);
+            CONV3P_DEEP_SHAPES(X)
+#undef X
+            if (rc != CONV3P_OK) return rc;
+            have_order = true;
+            if (c0 == 0)
+                hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(grid_1d(rows * kw)), dim3(256), 0, c.s, w.zp, grad_input + k0, rows,
+                                   kw, kwp, d.Cin);
+            else
+                hipLaunchKernelGGL(add_cols_kernel<float>, dim3(grid_1d(rows * kw)), dim3(256), 0, c.s, w.zp, grad_input + k0, rows,
+                                   kw, kwp, d.Cin);
+            hipLaunchKernelGGL(copy_block_kernel<float>, dim3(grid_1d((size_t)d.ntap * kw * cw)), dim3(256), 0, c.s, w.dwp,
+                               grad_filter + (size_t)k0 * d.Cout + c0, d.ntap, kw, cw, (size_t)kwp * cwp, cwp,
+                               (size_t)d.Cin * d.Cout, d.Cout);
+        }
+    }
+    return hip_ok();
+}
+
 int buf_check(const void *p, size_t have, size_t need)
 {
     if (need == 0) return CONV3P_OK;
@@ -980,6 +1125,7 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
         c.deep_scratch_ok = deep_shape((int)sizeof(T), d.Cin, d.Cout) &&
                             have >= deep_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
         c.tap_scratch_ok = tap_forward_shape((int)sizeof(T), d.Cin, d.Cout) && have >= tap_forward_bytes(d);
+        c.wide_scratch_ok = wide_shape((int)sizeof(T), d.Cin, d.Cout) && have >= wide_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
     }
     const unsigned long long tag = stencil_tag(d, stride, (double)voxel, (int)sizeof(T));
     if (!wh.persistent) {
@@ -1124,6 +1270,12 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     }
             CONV3P_DEEP_SHAPES(X)
 #undef X
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (c.wide_scratch_ok) {   // more than 256 channels on a side: blocks of <= 256 x 256 on the matrix-core kernels
+            const int rc = wide_forward(c, input, filter, output);
+            if (rc != CONV3P_ERR_UNSUPPORTED) return rc != CONV3P_OK || !act ? rc : selu_impl<T>(output, output, out_elems, stream);
         }
     }
     TRY(zero_async(output, out_elems * sizeof(T), s));                   // .cpp:451
@@ -1342,6 +1494,14 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
 #undef X
         }
     }
+    if constexpr (sizeof(T) == 4) {
+        if (rc == CONV3P_ERR_UNSUPPORTED && c.wide_scratch_ok) {
+            const int wrc = wide_backward(c, grad_out, input, filter, grad_input, grad_filter);
+            if (wrc != CONV3P_ERR_UNSUPPORTED)
+                return wrc != CONV3P_OK || !act ? wrc
+                           : selu_grad_impl<T>(input, grad_input, addend, grad_input, (size_t)B * N, Cin, nullptr, stream);
+        }
+    }
     bool generic = false;
     if (rc == CONV3P_ERR_UNSUPPORTED && c.strided) return rc;
     if (rc == CONV3P_ERR_UNSUPPORTED) {
@@ -1438,6 +1598,11 @@ size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, in
     }
     CONV3P_DEEP_SHAPES(X)
 #undef X
+    if (wide_shape(elem, max_Cin, max_Cout)) {
+        Dims dw{B, N, max_Cin, max_Cout, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};
+        const size_t need = wide_scratch_bytes(dw, (size_t)B * N * (size_t)ppp);
+        if (need > b) b = need;
+    }
     return b;
 }
 

@@ -1672,6 +1672,31 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(const T *src, T *dst, si
     }
 }
 
+// dst[r][0..cols) += src[r][0..cols)  (the later input-channel blocks of a wide layer, see conv3p_abi.hip wide_*)
+template <typename T>
+__global__ __launch_bounds__(256) void add_cols_kernel(const T *src, T *dst, size_t rows, int cols, int ld_s, int ld_d)
+{
+    const size_t n = rows * (size_t)cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (size_t)cols;
+        const int c = (int)(i - r * (size_t)cols);
+        dst[r * ld_d + c] += src[r * ld_s + c];
+    }
+}
+// dst[f][k][c] = src[f][k][c] for f < nf, k < nk, c < nc, with independent tap / row strides on both sides: a
+// [nk x nc] block of every tap of a filter <-> its packed copy
+template <typename T>
+__global__ __launch_bounds__(256) void copy_block_kernel(const T *src, T *dst, int nf, int nk, int nc, size_t sf_s, int sk_s,
+                                                         size_t sf_d, int sk_d)
+{
+    const size_t n = (size_t)nf * nk * nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / ((size_t)nk * nc), r = i - f * ((size_t)nk * nc);
+        const int k = (int)(r / nc), c = (int)(r - (size_t)k * nc);
+        dst[f * sf_d + (size_t)k * sk_d + c] = src[f * sf_s + (size_t)k * sk_s + c];
+    }
+}
+
 }  // namespace conv3p
 
 #include "conv3p_backward_sparse.hpp"
