@@ -297,12 +297,26 @@ inline size_t wide_scratch_bytes(const Dims &d, size_t pair_slots)
     return up(deep_scratch_bytes(db, pair_slots)) + 3 * up(rows * kWideBlk * 4) + 2 * up((size_t)d.ntap * kWideBlk * kWideBlk * 4);
 }
 
+// fp64 layers outside the register-path shapes (round 4): blocks of 16 input x 4 output channels, zero-padded, on the
+// register-path kernels <double, 16, 4> (their G matrix and transposed filter fit LDS in double) -- the op is linear
+// in the input-channel blocks and independent over the output-channel blocks -- instead of the global-atomics kernels.
+// Scratch: the block kernel's grad_filter partials, packed rows (input [B N][16], grad_out / result [B N][4] and
+// [B N][16]) and the packed filter block and its grad_filter block.
+constexpr int kF64Ki = 16, kF64Co = 4;
+inline bool f64_blocked_shape(int elem, int cin, int cout) { return elem == 8 && cin >= 1 && cout >= 1 && !small_shape(elem, cin, cout); }
+inline size_t f64_blocked_bytes(const Dims &d)
+{
+    const size_t rows = (size_t)d.B * d.N, nwb = (size_t)d.ntap * kF64Ki * kF64Co;
+    return up((size_t)grid_of(make_blockmap(d)) * nwb * 8) + 3 * up(rows * kF64Ki * 8) + 2 * up(nwb * 8);
+}
+
 // ppp: pair slots per point of the buffer the call runs in (a cache may be configured with fewer than the default)
 size_t backward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPerPoint)
 {
     const size_t nw = (size_t)d.ntap * d.Cin * d.Cout;
     size_t deep = 0;
     if (wide_shape(elem, d.Cin, d.Cout)) deep = wide_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+    if (f64_blocked_shape(elem, d.Cin, d.Cout)) deep = f64_blocked_bytes(d);
     if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
         deep = deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     // register path: one partial per workgroup; generic path (also the fallback of the other two): generic_slots
@@ -331,6 +345,7 @@ size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPer
     if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
         return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
     if (wide_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : wide_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+    if (f64_blocked_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : f64_blocked_bytes(d);
     return 0;
 }
 
@@ -358,6 +373,7 @@ template <typename T> struct Call {
     bool deep_scratch_ok = false;  // the scratch region can hold the deep path's side arrays
     bool tap_scratch_ok = false;   // ... the transform + gather forward's Z array
     bool wide_scratch_ok = false;  // ... the blocked path of layers with more than 256 channels
+    bool f64_scratch_ok = false;   // ... the blocked path of fp64 layers outside the register-path shapes
     bool order_ok[2] = {false, false};   // the deep path's forward / backward record order of this geometry is in the scratch
     void *cache_key = nullptr;     // persistent cache the call runs in (host bookkeeping of the record orders)
     uint64_t gen = 0;
@@ -1053,6 +1069,115 @@ int wide_backward(const Call<float> &c, const float *grad_out, const float *inpu
     return hip_ok();
 }
 
+// ----------------------------------------------------------------------------- fp64 layers outside the register-path shapes
+struct F64Scratch {
+    double *parts;          // the block kernel's grad_filter partials
+    double *xp, *yp, *zp;   // packed rows: input block [B N][16], grad_out block / forward result [B N][4], grad_input block [B N][16]
+    double *wp, *dwp;       // [ntap][16][4] filter block, its grad_filter block
+};
+inline F64Scratch carve_f64(const Call<double> &c)
+{
+    const Dims &d = c.d;
+    const size_t rows = (size_t)d.B * d.N, nwb = (size_t)d.ntap * kF64Ki * kF64Co;
+    char *p = reinterpret_cast<char *>(c.L.partials);
+    F64Scratch w{};
+    w.parts = reinterpret_cast<double *>(p); p += up((size_t)grid_of(make_blockmap(d)) * nwb * 8);
+    w.xp = reinterpret_cast<double *>(p); p += up(rows * kF64Ki * 8);
+    w.yp = reinterpret_cast<double *>(p); p += up(rows * kF64Ki * 8);
+    w.zp = reinterpret_cast<double *>(p); p += up(rows * kF64Ki * 8);
+    w.wp = reinterpret_cast<double *>(p); p += up(nwb * 8);
+    w.dwp = reinterpret_cast<double *>(p);
+    return w;
+}
+inline int f64_pack_rows(const Call<double> &c, const double *src, int ld_s, double *dst, size_t rows, int cols, int ldp)
+{
+    if (cols < ldp) TRY(zero_async(dst, rows * (size_t)ldp * 8, c.s));
+    hipLaunchKernelGGL(copy_cols_kernel<double>, dim3(grid_1d(rows * cols)), dim3(256), 0, c.s, src, dst, rows, cols, ld_s, ldp);
+    return CONV3P_OK;
+}
+inline int f64_pack_filter(const Call<double> &c, const double *filter, int k0, int kw, int c0, int cw, double *wp)
+{
+    const Dims &d = c.d;
+    if (kw < kF64Ki || cw < kF64Co) TRY(zero_async(wp, (size_t)d.ntap * kF64Ki * kF64Co * 8, c.s));
+    hipLaunchKernelGGL(copy_block_kernel<double>, dim3(grid_1d((size_t)d.ntap * kw * cw)), dim3(256), 0, c.s,
+                       filter + (size_t)k0 * d.Cout + c0, wp, d.ntap, kw, cw, (size_t)d.Cin * d.Cout, d.Cout,
+                       (size_t)kF64Ki * kF64Co, kF64Co);
+    return CONV3P_OK;
+}
+inline Call<double> f64_block_call(const Call<double> &c)
+{
+    Call<double> cp = c;
+    cp.d.Cin = kF64Ki;
+    cp.d.Cout = kF64Co;
+    cp.act = false;
+    cp.accum = false;
+    cp.addend = nullptr;
+    set_ld(cp, nullptr, kF64Ki, kF64Co);
+    return cp;
+}
+
+// out[:, c-block] = sum over the input-channel blocks (ascending) of the block kernel's result: deterministic
+int f64_blocked_forward(const Call<double> &c, const double *input, const double *filter, double *output)
+{
+    const Dims &d = c.d;
+    const size_t rows = (size_t)d.B * d.N;
+    const F64Scratch w = carve_f64(c);
+    const Call<double> cp = f64_block_call(c);
+    for (int k0 = 0; k0 < d.Cin; k0 += kF64Ki) {
+        const int kw = d.Cin - k0 < kF64Ki ? d.Cin - k0 : kF64Ki;
+        TRY(f64_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kF64Ki));
+        for (int c0 = 0; c0 < d.Cout; c0 += kF64Co) {
+            const int cw = d.Cout - c0 < kF64Co ? d.Cout - c0 : kF64Co;
+            TRY(f64_pack_filter(c, filter, k0, kw, c0, cw, w.wp));
+            TRY((launch_forward<double, kF64Ki, kF64Co>(cp, w.xp, w.wp, w.yp)));
+            if (k0 == 0)
+                hipLaunchKernelGGL(copy_cols_kernel<double>, dim3(grid_1d(rows * cw)), dim3(256), 0, c.s, w.yp, output + c0, rows, cw,
+                                   kF64Co, d.Cout);
+            else
+                hipLaunchKernelGGL(add_cols_kernel<double>, dim3(grid_1d(rows * cw)), dim3(256), 0, c.s, w.yp, output + c0, rows, cw,
+                                   kF64Co, d.Cout);
+        }
+    }
+    return hip_ok();
+}
+
+// grad_input[:, k-block] = sum over the output-channel blocks (ascending) of the block's grad_input; every block pair
+// gives its own block of grad_filter (per-workgroup partials, reduced in fixed order)
+int f64_blocked_backward(const Call<double> &c, const double *grad_out, const double *input, const double *filter,
+                         double *grad_input, double *grad_filter)
+{
+    const Dims &d = c.d;
+    const size_t rows = (size_t)d.B * d.N, nwb = (size_t)d.ntap * kF64Ki * kF64Co;
+    const int nslots = (int)grid_of(make_blockmap(d));
+    const F64Scratch w = carve_f64(c);
+    const Call<double> cp = f64_block_call(c);
+    for (int k0 = 0; k0 < d.Cin; k0 += kF64Ki) {
+        const int kw = d.Cin - k0 < kF64Ki ? d.Cin - k0 : kF64Ki;
+        TRY(f64_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kF64Ki));
+        for (int c0 = 0; c0 < d.Cout; c0 += kF64Co) {
+            const int cw = d.Cout - c0 < kF64Co ? d.Cout - c0 : kF64Co;
+            TRY(f64_pack_rows(c, grad_out + c0, d.Cout, w.yp, rows, cw, kF64Co));
+            TRY(f64_pack_filter(c, filter, k0, kw, c0, cw, w.wp));
+            TRY((launch_backward<double, kF64Ki, kF64Co>(cp, w.yp, w.xp, w.wp, w.zp, w.parts)));
+            {
+                Scope sc(K_REDUCE, c.s);
+                hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3((unsigned)((nwb + 63) / 64)), dim3(1024), 0, c.s, w.parts,
+                                   nslots, nwb, w.dwp);
+            }
+            if (c0 == 0)
+                hipLaunchKernelGGL(copy_cols_kernel<double>, dim3(grid_1d(rows * kw)), dim3(256), 0, c.s, w.zp, grad_input + k0, rows,
+                                   kw, kF64Ki, d.Cin);
+            else
+                hipLaunchKernelGGL(add_cols_kernel<double>, dim3(grid_1d(rows * kw)), dim3(256), 0, c.s, w.zp, grad_input + k0, rows,
+                                   kw, kF64Ki, d.Cin);
+            hipLaunchKernelGGL(copy_block_kernel<double>, dim3(grid_1d((size_t)d.ntap * kw * cw)), dim3(256), 0, c.s, w.dwp,
+                               grad_filter + (size_t)k0 * d.Cout + c0, d.ntap, kw, cw, (size_t)kF64Ki * kF64Co, kF64Co,
+                               (size_t)d.Cin * d.Cout, d.Cout);
+        }
+    }
+    return hip_ok();
+}
+
 int buf_check(const void *p, size_t have, size_t need)
 {
     if (need == 0) return CONV3P_OK;
@@ -1126,6 +1251,7 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
                             have >= deep_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
         c.tap_scratch_ok = tap_forward_shape((int)sizeof(T), d.Cin, d.Cout) && have >= tap_forward_bytes(d);
         c.wide_scratch_ok = wide_shape((int)sizeof(T), d.Cin, d.Cout) && have >= wide_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
+        c.f64_scratch_ok = f64_blocked_shape((int)sizeof(T), d.Cin, d.Cout) && have >= f64_blocked_bytes(d);
     }
     const unsigned long long tag = stencil_tag(d, stride, (double)voxel, (int)sizeof(T));
     if (!wh.persistent) {
@@ -1275,6 +1401,12 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     if constexpr (sizeof(T) == 4) {
         if (c.wide_scratch_ok) {   // more than 256 channels on a side: blocks of <= 256 x 256 on the matrix-core kernels
             const int rc = wide_forward(c, input, filter, output);
+            if (rc != CONV3P_ERR_UNSUPPORTED) return rc != CONV3P_OK || !act ? rc : selu_impl<T>(output, output, out_elems, stream);
+        }
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (c.f64_scratch_ok && !c.strided) {   // fp64 outside the register-path shapes: 16 x 4 channel blocks on <double, 16, 4>
+            const int rc = f64_blocked_forward(c, input, filter, output);
             if (rc != CONV3P_ERR_UNSUPPORTED) return rc != CONV3P_OK || !act ? rc : selu_impl<T>(output, output, out_elems, stream);
         }
     }
@@ -1502,6 +1634,14 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
                            : selu_grad_impl<T>(input, grad_input, addend, grad_input, (size_t)B * N, Cin, nullptr, stream);
         }
     }
+    if constexpr (sizeof(T) == 8) {
+        if (rc == CONV3P_ERR_UNSUPPORTED && c.f64_scratch_ok && !c.strided && !defer) {
+            const int brc = f64_blocked_backward(c, grad_out, input, filter, grad_input, grad_filter);
+            if (brc != CONV3P_ERR_UNSUPPORTED)
+                return brc != CONV3P_OK || !act ? brc
+                           : selu_grad_impl<T>(input, grad_input, addend, grad_input, (size_t)B * N, Cin, nullptr, stream);
+        }
+    }
     bool generic = false;
     if (rc == CONV3P_ERR_UNSUPPORTED && c.strided) return rc;
     if (rc == CONV3P_ERR_UNSUPPORTED) {
@@ -1598,6 +1738,10 @@ size_t cache_scratch_bytes(int elem, int B, int N, int max_taps, int max_Cin, in
     }
     CONV3P_DEEP_SHAPES(X)
 #undef X
+    if (elem == 8) {   // (any fp64 shape outside the register-path list may come: the blocked path's scratch)
+        Dims db{B, N, max_Cin, max_Cout, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};
+        if (f64_blocked_bytes(db) > b) b = f64_blocked_bytes(db);
+    }
     if (wide_shape(elem, max_Cin, max_Cout)) {
         Dims dw{B, N, max_Cin, max_Cout, 1, 1, max_taps, max_taps, (N + kTile - 1) / kTile};
         const size_t need = wide_scratch_bytes(dw, (size_t)B * N * (size_t)ppp);
