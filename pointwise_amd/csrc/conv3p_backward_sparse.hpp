@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
 
     const int32_t *cnt_cloud = count + (size_t)b * N * st.ntap;
     const T *dy_cloud = grad_out + (size_t)b * N * ld.dy;
-    T *dx_cloud = grad_input + (size_t)b * N * ld.dx;
     const uint64_t lt_cq = cq == 0 ? 0ull : (~0ull >> (64 - cq));
     const int orig_lane = me.idx;   // (the rest of `me` is only needed by the overflow path, which reloads it)
     const int nrounds = (int)rinfo[0];
