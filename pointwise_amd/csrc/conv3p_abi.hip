@@ -923,7 +923,7 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
     TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds, d.Cout, d.Cin, ds.gbuf, input)));
     {
         constexpr int NH = CO >= 64 ? 2 : 1;
-        const size_t lds = (size_t)64 * (CI + 1) * 4 + (size_t)64 * (CO / NH + 1) * 4 + 256;
+        const size_t lds = (size_t)DEEP_DW_ROWS * (CI + 1) * 4 + (size_t)DEEP_DW_ROWS * (CO / NH + 1) * 4 + 256;
         if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
         Scope sc(K_DEEP_DW, c.s);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deep_dw_kernel<CI, CO>),

@@ -37,6 +37,12 @@
 #ifndef DEEP_SKIP_STORES
 #define DEEP_SKIP_STORES 1
 #endif
+#ifndef DEEP_DW_ROWS
+#define DEEP_DW_ROWS 32   // packed rows of a tile that deep_dw_kernel holds in LDS at a time (64: all)
+#endif
+#ifndef DEEP_DW_WAVES
+#define DEEP_DW_WAVES (DEEP_DW_ROWS == 64 ? 2 : 3)
+#endif
 #ifndef DEEP_KU
 #define DEEP_KU 4   // records per pipeline step of deep_gemm_kernel's stage 1
 #endif
@@ -980,7 +986,7 @@ __global__ __launch_bounds__(256) void deep_reduce_kernel(const float *__restric
 // LDS: X tile [64][CIN+1] | G tile [64][cols+1] | qorig [64]   (<= 66 KB: two workgroups per CU)
 // ---------------------------------------------------------------------------------------------
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void deep_dw_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_DW_WAVES))) void deep_dw_kernel(
     const PointRec<float> *__restrict__ pts, const uint32_t *__restrict__ tap_off, const float *__restrict__ gbuf,
     const float *__restrict__ input, int N, int ntiles, int ntap, const uint8_t *__restrict__ tile_flag,
     const uint4 *__restrict__ items, const uint32_t *__restrict__ nitems, float *__restrict__ partials,
@@ -995,9 +1001,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     constexpr int PM = (MB + WM - 1) / WM, PN = NB / WN;   // blocks per wave along each axis
     static_assert(CIN % 32 == 0 && CH % 32 == 0 && NB % WN == 0, "deep path: channel counts are 32 or multiples of 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *X = reinterpret_cast<float *>(smem);            // [64][LDX]
-    float *G = X + 64 * LDX;                               // [64][LDG]
-    int32_t *qorig = reinterpret_cast<int32_t *>(G + 64 * LDG);
+    constexpr int kRows = DEEP_DW_ROWS;                    // packed rows per pass
+    float *X = reinterpret_cast<float *>(smem);            // [kRows][LDX]
+    float *G = X + kRows * LDX;                            // [kRows][LDG]
+    int32_t *qorig = reinterpret_cast<int32_t *>(G + kRows * LDG);
     if (blockIdx.x >= *nitems) return;
     const uint4 item = items[blockIdx.x];                  // {tap, first tile, end tile, partial slot}
     const int f = (int)item.x, c0 = (int)blockIdx.y * CH;
@@ -1012,6 +1019,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // A tile's packed rows (the centres that have the tap: 27 of 64 on average) go through LDS kRows at a time: with
+    // room for all 64 the two tiles took 66 KiB (two workgroups per CU, 50 % matrix-pipe busy: a workgroup's loads are
+    // exposed, only the CU's other workgroup covers them); 32 rows take 33 KiB, three workgroups per CU (the
+    // registers' limit), and most tiles still need one pass.
     for (size_t tile = item.y; tile < item.z; ++tile) {
         const uint32_t *toff = tap_off + tile * (size_t)(ntap + 1);
         if (toff[f] == toff[f + 1] || tile_flag[tile]) continue;   // uniform: nothing with this tap / generic kernel's tile
@@ -1020,75 +1031,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
         // enter the contraction; K is padded to a multiple of 8 with zero rows of G
         const unsigned long long cm = tap_cmask[tile * (size_t)ntap + f];
         const int nrow = __popcll(cm), npad = (nrow + 7) & ~7;
-        __syncthreads();                                    // previous tile's X / G consumed
+        __syncthreads();                                    // previous tile's X / G consumed (qorig too)
         if (wave == 0) {
             const int orig = pts[tile * kTile + lane].idx;
             if ((cm >> lane) & 1ull) qorig[__popcll(cm & ((1ull << lane) - 1ull))] = orig;   // packed row -> original index
         }
-        // G tile half: [nrow][CH] of the stored block (16-byte loads, all of a thread's in flight together)
-        {
-            const float *gt = gbuf + (tile * (size_t)ntap + f) * 64 * COUT + c0;
-            constexpr int GPT = (64 * (CH / 4)) / 256;       // float4 per thread
-            float4 gv[GPT];
+        for (int r0 = 0; r0 < npad; r0 += kRows) {
+            const int cr = npad - r0 < kRows ? npad - r0 : kRows;   // rows of this pass (a multiple of 8)
+            if (r0 > 0) __syncthreads();                    // previous pass consumed
+            // G rows r0 .. r0 + cr of the stored block half (16-byte loads, all of a thread's in flight together)
+            {
+                const float *gt = gbuf + (tile * (size_t)ntap + f) * 64 * COUT + c0;
+                constexpr int GPT = (kRows * (CH / 4)) / 256;   // float4 per thread
+                float4 gv[GPT];
 #pragma unroll
-            for (int u = 0; u < GPT; ++u) {
-                const int e = (int)threadIdx.x + 256 * u;
-                const int rr = e / (CH / 4);
-                gv[u] = *reinterpret_cast<const float4 *>(gt + (size_t)(rr < nrow ? rr : 0) * COUT + 4 * (e % (CH / 4)));
-            }
-#pragma unroll
-            for (int u = 0; u < GPT; ++u) {
-                const int e = (int)threadIdx.x + 256 * u;
-                const int rr = e / (CH / 4);
-                if (rr < npad) {
-                    float *gr = G + rr * LDG + 4 * (e % (CH / 4));
-                    const bool on = rr < nrow;
-                    gr[0] = on ? gv[u].x : 0.f; gr[1] = on ? gv[u].y : 0.f; gr[2] = on ? gv[u].z : 0.f; gr[3] = on ? gv[u].w : 0.f;
-                }
-            }
-        }
-        __syncthreads();                                    // qorig visible
-        {
-            constexpr int XPT = (64 * (CIN / 4)) / 256;      // float4 per thread (CIN >= 32)
-            float4 xv[XPT];
-#pragma unroll
-            for (int u = 0; u < XPT; ++u) {
-                const int e = (int)threadIdx.x + 256 * u;
-                const int rr = e / (CIN / 4);
-                const int orig = rr < nrow ? qorig[rr] : -1;
-                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (orig >= 0) xv[u] = load_row4(input + ((size_t)b * N + orig) * cin, 4 * (e % (CIN / 4)), cin);
-            }
-#pragma unroll
-            for (int u = 0; u < XPT; ++u) {
-                const int e = (int)threadIdx.x + 256 * u;
-                if (e / (CIN / 4) < npad) {
-                    float *xr = X + (e / (CIN / 4)) * LDX + 4 * (e % (CIN / 4));
-                    xr[0] = xv[u].x; xr[1] = xv[u].y; xr[2] = xv[u].z; xr[3] = xv[u].w;
-                }
-            }
-        }
-        __syncthreads();
-        if (w_on) {
-            // A[i = k][kk = row] = X[row][k], B[kk = row][j = c] = G[row][c]: npad / 2 k-steps, 4 at a time
-            const float *xa = X + half * LDX + wm * PM * 32 + (lane & 31);
-            const float *gb = G + half * LDG + wn * PN * 32 + (lane & 31);
-            for (int s4 = 0; s4 < npad / 2; s4 += 4) {
-                float a[4][PM], bv[4][PN];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                    for (int i = 0; i < PM; ++i) a[t][i] = xa[2 * (s4 + t) * LDX + i * 32];
-#pragma unroll
-                    for (int j = 0; j < PN; ++j) bv[t][j] = gb[2 * (s4 + t) * LDG + j * 32];
+                for (int u = 0; u < GPT; ++u) {
+                    const int e = (int)threadIdx.x + 256 * u;
+                    const int rr = r0 + e / (CH / 4);
+                    gv[u] = *reinterpret_cast<const float4 *>(gt + (size_t)(rr < nrow ? rr : 0) * COUT + 4 * (e % (CH / 4)));
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int u = 0; u < GPT; ++u) {
+                    const int e = (int)threadIdx.x + 256 * u;
+                    const int rl = e / (CH / 4);
+                    if (rl < cr) {
+                        float *gr = G + rl * LDG + 4 * (e % (CH / 4));
+                        const bool on = r0 + rl < nrow;
+                        gr[0] = on ? gv[u].x : 0.f; gr[1] = on ? gv[u].y : 0.f; gr[2] = on ? gv[u].z : 0.f; gr[3] = on ? gv[u].w : 0.f;
+                    }
+                }
+            }
+            if (r0 == 0) __syncthreads();                   // qorig visible
+            {
+                constexpr int XPT = (kRows * (CIN / 4)) / 256;   // float4 per thread (CIN >= 32)
+                float4 xv[XPT];
 #pragma unroll
-                    for (int i = 0; i < PM; ++i)
+                for (int u = 0; u < XPT; ++u) {
+                    const int e = (int)threadIdx.x + 256 * u;
+                    const int rr = r0 + e / (CIN / 4);
+                    const int orig = rr < nrow ? qorig[rr] : -1;
+                    xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (orig >= 0) xv[u] = load_row4(input + ((size_t)b * N + orig) * cin, 4 * (e % (CIN / 4)), cin);
+                }
 #pragma unroll
-                        for (int j = 0; j < PN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][i], bv[t][j], acc[i][j], 0, 0, 0);
+                for (int u = 0; u < XPT; ++u) {
+                    const int e = (int)threadIdx.x + 256 * u;
+                    if (e / (CIN / 4) < cr) {
+                        float *xr = X + (e / (CIN / 4)) * LDX + 4 * (e % (CIN / 4));
+                        xr[0] = xv[u].x; xr[1] = xv[u].y; xr[2] = xv[u].z; xr[3] = xv[u].w;
+                    }
+                }
+            }
+            __syncthreads();
+            if (w_on) {
+                // A[i = k][kk = row] = X[row][k], B[kk = row][j = c] = G[row][c]: cr / 2 k-steps, 4 at a time
+                const float *xa = X + half * LDX + wm * PM * 32 + (lane & 31);
+                const float *gb = G + half * LDG + wn * PN * 32 + (lane & 31);
+                for (int s4 = 0; s4 < cr / 2; s4 += 4) {
+                    float a[4][PM], bv[4][PN];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int i = 0; i < PM; ++i) a[t][i] = xa[2 * (s4 + t) * LDX + i * 32];
+#pragma unroll
+                        for (int j = 0; j < PN; ++j) bv[t][j] = gb[2 * (s4 + t) * LDG + j * 32];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < PM; ++i)
+#pragma unroll
+                            for (int j = 0; j < PN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][i], bv[t][j], acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
