@@ -791,7 +791,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             for (int r = 0; r < 16; ++r) badsum += acc[i][r] - acc[i][r];
     }
     const bool bad = __syncthreads_or(!(badsum == 0.0f)) != 0;
-    if (bad && threadIdx.x == 0) tile_flag[tile_id] = 1;   // zero rows now, exact accumulation by the generic kernel
+    // bad: zero rows now, exact accumulation by the generic kernel.  The flag is rewritten by EVERY pass over the tile:
+    // the record order (and with it this array) outlives the call when the geometry is reused -- a later call with
+    // finite data, or the next channel block of a wide layer, must not find the mark of an earlier one (the generic
+    // kernel would add its result to rows this kernel has filled).  (Overflowed tiles returned above: their mark, set
+    // by deep_order_kernel, stays.)
+    if (threadIdx.x == 0) tile_flag[tile_id] = bad ? 1 : 0;
     if (o_on) {
 #pragma unroll
         for (int i = 0; i < RBW; ++i)

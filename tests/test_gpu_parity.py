@@ -962,6 +962,74 @@ def test_deep_channel_path_non_finite_values_reach_only_their_neighbours(dev):
         assert np.max(np.abs(got[ok] - ref[ok])) <= tol * max(1.0, np.max(np.abs(ref[ok])))
 
 
+def test_deep_channel_path_forgets_the_non_finite_mark_of_an_earlier_call(dev):
+    """The matrix-core path marks tiles that met Inf / NaN for the exact kernel; the mark lives with the record order,
+    which a later call on the same points (CONV3P_CACHE_POINTS_UNCHANGED) reuses.  That call, with finite data, must
+    not find the tiles still marked (the exact kernel would add its result to rows the matrix-core kernel has filled --
+    found in round 4 through the channel-blocked path, where the next block is such a call)."""
+    B, N, ci, co = 1, 400, 32, 64
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=1450)
+    Xbad = X.copy(); Xbad[0, 50, 2] = np.nan
+    dYbad = dY.copy(); dYbad[0, 60, 1] = np.inf
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    s = (1, 1, 1)
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
+    op.conv3p(t(P), t(Xbad), t(W), s, VOX, cache=cache)
+    y = op.conv3p(t(P), t(X), t(W), s, VOX, cache=cache, points_unchanged=True)
+    op.conv3p_grad(t(dYbad), t(P), t(Xbad), t(W), s, VOX, cache=cache, points_unchanged=True)
+    dx, dw = op.conv3p_grad(t(dY), t(P), t(X), t(W), s, VOX, cache=cache, points_unchanged=True)
+    assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, s, VOX)) <= 1e-5
+    dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, VOX)
+    assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
+
+
+@pytest.mark.parametrize("ci,co,dt", [(300, 70, np.float32), (17, 3, np.float64), (40, 9, np.float64)])
+def test_blocked_paths_non_finite_values_and_pair_buffer_overflow(dev, ci, co, dt):
+    """The channel-blocked paths of round 4 (more than 256 channels on the matrix-core kernels, fp64 outside the
+    register-path shapes on <double, 16, 4>): Inf / NaN inputs land on exactly the outputs they reach in the reference
+    (zero padding of the blocks must not turn them into extra NaNs), and a cache whose pair buffer overflows still gives
+    the reference's results."""
+    B, N = 2, 300
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=1400, dtype=dt)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    tol_y, tol_w = (1e-5, 2e-5) if dt == np.float32 else (1e-12, 1e-12)
+    s = (1, 1, 1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # pair-buffer overflow: tiles search themselves / are handed to the exact kernels
+    cache = op.NeighborCache(B, N, tdt, dev, slots=1, max_taps=27, pairs_per_point=4, max_cin=ci, max_cout=co)
+    y, dx, dw = _both(dev, cache, P, X, W, dY, s)
+    assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, s, VOX)) <= tol_y
+    dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, VOX)
+    assert rel_err(dx.cpu().numpy(), dx_ref) <= tol_y and rel_err(dw.cpu().numpy(), dw_ref) <= tol_w
+    # non-finite values
+    X = X.copy(); dY = dY.copy()
+    X[0, 17, 3] = np.inf
+    X[1, 200, ci - 1] = np.nan
+    dY[0, 99, co - 1] = np.inf
+    with np.errstate(all="ignore"):
+        y_ref = oracle.forward(P, X, W, s, VOX)
+        dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, VOX)
+    y = op.conv3p(t(P), t(X), t(W), s, VOX).cpu().numpy()
+    dx, dw = op.conv3p_grad(t(dY), t(P), t(X), t(W), s, VOX)
+    for name, got, ref, tol in (("y", y, y_ref, tol_y), ("dx", dx.cpu().numpy(), dx_ref, tol_y), ("dw", dw.cpu().numpy(), dw_ref, tol_w)):
+        bad_ref = ~np.isfinite(ref)
+        bad_got = ~np.isfinite(got)
+        assert bad_ref.any() and not bad_ref.all()
+        if name == "dw" and dt == np.float64:
+            # the dense-G register kernels contract G (zero where a centre has no pair with the tap) with ALL 64 input
+            # rows of the tile: a non-finite input channel k marks grad_filter[:, k, :] for every tap (0 x NaN), the
+            # reference only for the taps the point takes part in (DESIGN.md section 2) -- a superset, nothing else
+            assert np.all(bad_got[bad_ref]) and not bad_got.all()
+            extra = bad_got & ~bad_ref
+            keep = np.ones(ci, dtype=bool)
+            keep[[3, ci - 1]] = False                      # the two input channels that hold the non-finite values
+            assert not extra[..., keep, :].any()
+        else:
+            assert np.array_equal(bad_got, bad_ref)
+        ok = ~bad_got
+        assert np.max(np.abs(got[ok] - ref[ok])) <= 10 * tol * max(1.0, np.max(np.abs(ref[ok])))
+
+
 def _fuzz_cases():
     rng = np.random.RandomState(20260927)
     shapes = [(3, 9), (9, 9), (36, 13), (5, 7), (1, 1), (32, 64), (64, 64), (9, 3), (12, 9), (2, 17)]
