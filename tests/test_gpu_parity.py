@@ -816,7 +816,8 @@ def test_tile_schedule_is_a_permutation_and_results_do_not_depend_on_it(dev):
 
 # ------------------------------------------------------------------ fused conv3p + SELU layer ops
 @pytest.mark.parametrize("ci,co,dt", [(9, 9, np.float32), (3, 9, np.float32), (5, 7, np.float32), (32, 64, np.float32),
-                                      (5, 7, np.float64), (36, 13, np.float64), (36, 13, np.float32)])
+                                      (5, 7, np.float64), (36, 13, np.float64), (36, 13, np.float32), (260, 30, np.float32),
+                                      (20, 6, np.float64)])
 def test_layer_ops_equal_unfused_sequence(dev, ci, co, dt):
     """conv3p_layer == selu(conv3p); conv3p_layer_grad == selu_grad(input, dX + addend), on every kernel family
     (register path, generic path, deep path, fp64)."""
@@ -960,6 +961,29 @@ def test_deep_channel_path_non_finite_values_reach_only_their_neighbours(dev):
         assert np.array_equal(~np.isfinite(got), bad_ref)
         ok = ~bad_ref
         assert np.max(np.abs(got[ok] - ref[ok])) <= tol * max(1.0, np.max(np.abs(ref[ok])))
+
+
+def test_blocked_wide_layer_on_a_persistent_cache_with_prepared_orders_and_several_strides(dev):
+    """A layer of more than 256 channels on one persistent cache: geometry and both record orders built ahead
+    (conv3p_cache_prepare with CONV3P_CACHE_PREPARE_DEEP_ORDERS), then the layer's calls with the points-unchanged
+    promise, a second stencil in between (the orders in the scratch are then rebuilt), and the first stencil again --
+    every result bit for bit the stateless one."""
+    B, N, ci, co = 2, 350, 270, 40
+    P, X, W, dY = make_case("room", B, N, ci, co, seed=1460)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tp, tx, tw, tdy = t(P), t(X), t(W), t(dY)
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=2, max_taps=27, max_cin=ci, max_cout=co)
+    ref = {}
+    for s in ((1, 1, 1), (2, 2, 2)):
+        y = op.conv3p(tp, tx, tw, s, VOX)
+        dx, dw = op.conv3p_grad(tdy, tp, tx, tw, s, VOX)
+        ref[s] = (y, dx, dw)
+    op.cache_prepare(tp, (3, 3, 3), (1, 1, 1), VOX, cache, deep_orders=True)
+    for i, s in enumerate(((1, 1, 1), (1, 1, 1), (2, 2, 2), (1, 1, 1), (2, 2, 2))):
+        y = op.conv3p(tp, tx, tw, s, VOX, cache=cache, points_unchanged=True)
+        dx, dw = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=cache, points_unchanged=True)
+        for u, v in zip((y, dx, dw), ref[s]):
+            assert torch.equal(u, v), (i, s)
 
 
 def test_deep_channel_path_forgets_the_non_finite_mark_of_an_earlier_call(dev):
