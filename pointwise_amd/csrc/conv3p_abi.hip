@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -602,6 +603,70 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
     return hip_ok();
 }
 
+#ifdef CONV3P_DEV_WALK_STATS
+// developer instrumentation build only (-DCONV3P_DEV_WALK_STATS, tools/walk_stats.py): how well the list-walking kernels'
+// lane mapping uses a wave.  Per query tile, from the per-centre segment table: records, steps of the shipped mapping
+// (wave = 16 centres x 4 sub-lanes: ceil(longest list / 4)), steps with the lanes of a wave dealt to its centres in
+// proportion to their lists, the same over the whole workgroup, and the bound ceil(records / 64).
+__global__ void walk_stats_kernel(const uint2 *qsegs, const PairEntry *pairs, int ntiles_all, unsigned long long *out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles_all) return;
+    uint32_t len[64];
+    unsigned long long recs = 0, live = 0;
+    for (int c = 0; c < 64; ++c) {
+        const uint2 sg = qsegs[(size_t)t * 64 + c];
+        len[c] = sg.y == kSegOverflow ? 0u : sg.y;
+        recs += len[c];
+        for (uint32_t i = 0; i < len[c]; ++i) live += code_fwd(pairs[sg.x + i].code) != kNoTap ? 1u : 0u;
+    }
+    unsigned long long cur = 0, pslw = 0, ideal = 0, curmax = 0, pslmax = 0, idealmax = 0;
+    for (int w = 0; w < 4; ++w) {
+        uint32_t mx = 0, sum = 0;
+        for (int c = 0; c < 16; ++c) { mx = max(mx, len[16 * w + c]); sum += len[16 * w + c]; }
+        const unsigned long long a = (mx + 3) / 4;
+        uint32_t S = max(1u, (sum + 63) / 64);
+        for (;; ++S) {
+            uint32_t need = 0;
+            for (int c = 0; c < 16; ++c) need += (len[16 * w + c] + S - 1) / S;
+            if (need <= 64) break;
+        }
+        const unsigned long long idl = (sum + 63) / 64;
+        cur += a; pslw += S; ideal += idl;
+        curmax = max(curmax, a); pslmax = max(pslmax, (unsigned long long)S); idealmax = max(idealmax, idl);
+    }
+    uint32_t St = max(1u, (uint32_t)((recs + 255) / 256));
+    for (;; ++St) {
+        uint32_t need = 0;
+        for (int c = 0; c < 64; ++c) need += (len[c] + St - 1) / St;
+        if (need <= 256) break;
+    }
+    atomicAdd(&out[0], recs); atomicAdd(&out[1], live); atomicAdd(&out[2], cur); atomicAdd(&out[3], pslw);
+    atomicAdd(&out[4], 4ull * St); atomicAdd(&out[5], ideal);
+    atomicMax(&out[6], curmax); atomicMax(&out[7], pslmax); atomicMax(&out[8], (unsigned long long)St); atomicMax(&out[9], idealmax);
+}
+template <typename T> void dev_walk_stats(const Call<T> &c, const char *what, int ci, int co)
+{
+    const auto &S = c.L.slot[c.slot];
+    if (c.L.ngroups != 1) return;
+    unsigned long long *d = nullptr, h[10];
+    if (hipMalloc(&d, sizeof(h)) != hipSuccess) return;
+    (void)hipMemsetAsync(d, 0, sizeof(h), c.s);
+    const int nt = c.d.B * c.d.ntiles;
+    hipLaunchKernelGGL(walk_stats_kernel, dim3((nt + 63) / 64), dim3(64), 0, c.s, S.qsegs, S.pairs, nt, d);
+    (void)hipStreamSynchronize(c.s);
+    (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    const double r = (double)h[0];
+    fprintf(stderr, "walk_stats %s<%d,%d> stride %d B=%d N=%d: records/point %.2f (true pairs %.2f) | lane use: shipped %.3f (true-pair %.3f), "
+            "per-wave proportional %.3f, per-workgroup proportional %.3f, bound %.3f | steps of the slowest wave: shipped %llu, "
+            "per-wave prop. %llu, per-wg prop. %llu, bound %llu | mean steps per wave: %.2f / %.2f / %.2f / %.2f\n",
+            what, ci, co, c.st.step[0], c.d.B, c.d.N, r / ((double)c.d.B * c.d.N), (double)h[1] / ((double)c.d.B * c.d.N),
+            r / (64.0 * h[2]), (double)h[1] / (64.0 * h[2]), r / (64.0 * h[3]), r / (64.0 * h[4]), r / (64.0 * h[5]),
+            h[6], h[7], h[8], h[9], h[2] / (4.0 * nt), h[3] / (4.0 * nt), h[4] / (4.0 * nt), h[5] / (4.0 * nt));
+}
+#endif
+
 template <typename T, int CI, int CO>
 int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output, const uint8_t *only_flagged = nullptr)
 {
@@ -616,6 +681,9 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
             const BlockMap bm = make_blockmap(d);
             const size_t glds = lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + 256 +
                                 a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * CO * 64 * 4);
+#ifdef CONV3P_DEV_WALK_STATS
+            dev_walk_stats(c, "tap_gather_kernel", CI, CO);
+#endif
             Scope sc(K_FORWARD, c.s);
             hipLaunchKernelGGL((tap_transform_kernel<CI, CO>), dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, c.s, input,
                                filter, z, rows, st.ntap, c.ld.in);
@@ -627,12 +695,15 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
             return hip_ok();
         }
     }
-    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * ((CI * CO) | 1) * sizeof(T)) : 0) +
+    const size_t lds = lds_common(st) + (CI > 0 ? a16((size_t)st.ntap * fwd_wstr<T>(CI, CO) * sizeof(T)) : 0) +
                        a16((size_t)st.ntap * kCntStride * sizeof(T)) +
                        256 + a16((size_t)kWavesPerBlock * 192 * 4) +
                        (CI > 0 ? a16((size_t)kWavesPerBlock * CO * 64 * sizeof(T)) : 0);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
     const BlockMap bm = make_blockmap(d);
+#ifdef CONV3P_DEV_WALK_STATS
+    if (CI > 0) dev_walk_stats(c, "forward_kernel", CI, CO);
+#endif
     Scope sc(K_FORWARD, c.s);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(forward_kernel<T, CI, CO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -28,8 +28,8 @@
 #ifndef CONV3P_SP_DEPTH_WIDE
 #define CONV3P_SP_DEPTH_WIDE 4   // phase A gather depth of the >= 16-input layers (2 waves per SIMD: 256 registers)
 #endif
-#ifndef CONV3P_SP_TURNS
-#define CONV3P_SP_TURNS 1   // developer A/B: 0 = equal-tap sub-lanes merged by lane swaps before one read-modify-write
+#ifndef CONV3P_SP_BLOCKED
+#define CONV3P_SP_BLOCKED 1   // developer A/B: 0 = the lanes of a centre take its records interleaved (1: one run each)
 #endif
 #ifndef CONV3P_SP_CHSPLIT
 #define CONV3P_SP_CHSPLIT 1   // developer A/B: 0 = a centre's sub-lanes take different records (merged by lane swaps)
@@ -95,9 +95,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
     T *red = G;                                                   // [4][CIN][64]: ALIASES G (used after the last round)
     // narrow layers: sub-lanes of a centre 16 lanes apart (their merge swaps 16- / 32-lane blocks); wide layers: ADJACENT
     // lanes, so that their pieces of one dY row and their common record form one access for the texture addresser
+    // narrow layers: the lanes of the wave are dealt to its 16 centres in proportion to their lists (share_lanes; four
+    // consecutive lanes per centre when the cloud was searched in several groups) and every lane walks its own run of
+    // the list; wide layers: four ADJACENT lanes walk a centre's list together and split the output channels, so that
+    // their pieces of one dY row and their common record form one access for the texture addresser
     constexpr bool kChSplit = CONV3P_SP_CHSPLIT && CIN >= 16;
-    const int cq = kChSplit ? wave * 16 + (lane >> 2) : wave * 16 + (lane & 15), sub = kChSplit ? (lane & 3) : (lane >> 4);
+    int cq = wave * 16 + (lane >> 2);
+    uint32_t sub = lane & 3u, maxn = 4u;
+    uint32_t *share = reinterpret_cast<uint32_t *>(soa);   // the wave's lane-sharing scratch (soa is the overflow path's)
 
+#if CONV3P_SP_ABLATE & 128
+    long long st_[10];
+    int sti_ = 0;
+#define SDBG() { __builtin_amdgcn_s_waitcnt(0); st_[sti_++] = wall_clock64(); }
+#else
+#define SDBG()
+#endif
+    SDBG()
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
 
@@ -112,13 +126,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
     const uint32_t bm_raw = qbm[tile_id * 64 + lane];
     bool overflow = false;
     for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
-    const uint2 sg0 = qsegs[(tile_id * ngroups) * 64 + cq];
+    LaneShare ls0;
+    if (!kChSplit && ngroups == 1) {
+        ls0 = share_lanes(qsegs[tile_id * 64 + wave * 16 + (lane & 15)], share);
+        cq = wave * 16 + (int)ls0.cl;
+        sub = ls0.r;
+        maxn = ls0.maxn;
+    } else {
+        ls0 = share_lanes_uniform(qsegs[(tile_id * ngroups) * 64 + cq]);
+    }
+    const uint2 sg0 = ls0.seg;
+    const LaneWalk wk0 = lane_walk(ls0, CONV3P_SP_BLOCKED != 0);
     constexpr int kDepth = CIN < 16 ? CONV3P_SP_DEPTH_NARROW : CONV3P_SP_DEPTH_WIDE;   // records in flight per lane in phase A
     PairEntry rec0[kDepth - 1];
 #pragma unroll
     for (int sl = 0; sl < kDepth - 1; ++sl) {
-        const uint32_t i0 = kChSplit ? (uint32_t)sl : (uint32_t)(sub + 4 * sl);
-        rec0[sl] = pairs[sg0.x + (i0 < sg0.y && sg0.y != kSegOverflow ? i0 : 0u)];
+        const uint32_t i0 = kChSplit ? (uint32_t)sl : wk0.i + wk0.step * (uint32_t)sl;
+        const uint32_t e0 = kChSplit ? sg0.y : wk0.end;
+        rec0[sl] = pairs[sg0.x + (i0 < e0 && sg0.y != kSegOverflow ? i0 : 0u)];
     }
     if (wave == 0) {
         qorig[lane] = me.idx;
@@ -253,18 +278,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
             }
         } else if (!overflow) {
             for (int g = 0; g < ngroups; ++g) {
-                const uint2 sg = g == 0 ? sg0 : qsegs[(tile_id * ngroups + g) * 64 + cq];
+                LaneShare lsg = ls0;
+                if (g > 0) lsg.seg = qsegs[(tile_id * ngroups + g) * 64 + cq];
+                const uint2 sg = lsg.seg;
+                const LaneWalk wk = g == 0 ? wk0 : lane_walk(lsg, CONV3P_SP_BLOCKED != 0);
                 const PairEntry *pe = pairs + sg.x;
                 auto live_rec = [&](const PairEntry &rc, uint32_t i) {
                     const uint32_t fb = code_bwd(rc.code);
-                    return i < sg.y && code_fwd(rc.code) != kNoTap && fb != kNoTap && (int)fb >= t0 && (int)fb < t1;
+                    return i < wk.end && code_fwd(rc.code) != kNoTap && fb != kNoTap && (int)fb >= t0 && (int)fb < t1;
                 };
                 PairEntry rec[kDepth];
                 bool lv[kDepth];
                 int cn[kDepth];
                 uint32_t row[kDepth];   // G row of the record's (centre, tap): looked up when the record arrives
                 T val[kDepth][COUT];
-                auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
+                auto ld_rec = [&](uint32_t i) { return pe[i < wk.end ? i : 0u]; };
                 auto gather = [&](int sl, uint32_t i) {
                     lv[sl] = live_rec(rec[sl], i);
                     row[sl] = slot_of(lv[sl] ? code_bwd(rec[sl].code) : (uint32_t)t0, lt_cq);
@@ -278,23 +306,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
                     RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] && !(CONV3P_SP_ABLATE & 32) ? rec[sl].cand : 0u) * ld.dy, val[sl]);
                 };
 #pragma unroll
-                for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = g == 0 ? rec0[sl] : ld_rec(sub + 4 * sl);
+                for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = g == 0 ? rec0[sl] : ld_rec(wk.i + wk.step * sl);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, sub + 4 * sl);
-                uint32_t i = sub;
+                for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, wk.i + wk.step * sl);
+                uint32_t i = wk.i;
                 bool more = true;
                 while (more) {
 #pragma unroll
                     for (int j = 0; j < kDepth; ++j) {
-                        if (!__any(i < sg.y)) {
+                        if (!__any(i < wk.end)) {
                             more = false;
                             break;
                         }
-                        rec[(j + kDepth - 1) % kDepth] = ld_rec(i + 4 * (kDepth - 1));
-                        gather((j + kDepth - 2) % kDepth, i + 4 * (kDepth - 2));
+                        rec[(j + kDepth - 1) % kDepth] = ld_rec(i + wk.step * (kDepth - 1));
+                        gather((j + kDepth - 2) % kDepth, i + wk.step * (kDepth - 2));
                         __builtin_amdgcn_sched_barrier(0);
-                        bool pending = lv[j] & (cn[j] != 0);                                   // .cpp:679
+                        const bool pending = lv[j] & (cn[j] != 0);                             // .cpp:679
                         const uint32_t fb = code_bwd(rec[j].code);
                         T(&v)[COUT] = val[j];
                         if (pending) {
@@ -302,21 +330,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
 #pragma unroll
                             for (int c = 0; c < COUT; ++c) v[c] *= rcpb;
                         }
-#if CONV3P_SP_TURNS
-                        // Sub-lanes of one centre that meet on a tap take TURNS at its row of G, lower sub-lane first:
-                        // turn = number of lower sub-lanes with the same tap (three swaps of the tap alone); a wave's
-                        // LDS accesses execute in program order, so turn p adds to what turn p - 1 wrote.  (Before:
-                        // the lower lane absorbed the higher one's 9 values through lane swaps -- 40 swaps and 75
-                        // selects per step, half of phase A's 290 vector instructions per step, and phase A is bound
-                        // by exactly that count: 4 waves per SIMD x 290 x 4 cycles = the measured 1.9 us per step.)
+                        // Lanes of one centre that meet on a tap take TURNS at its row of G, lower lane first: turn = number
+                        // of lower lanes of the centre with the same tap; a wave's LDS accesses execute in program order, so
+                        // turn p adds to what turn p - 1 wrote -- race-free, in a fixed order.
                         {
-                            const uint32_t mine_fb = pending ? fb : kNoTap;
-                            const uint32_t f1 = lane_xor16(mine_fb), f2 = lane_xor32(mine_fb), f3 = lane_xor32(f1);
-                            const int turn = ((sub & 1) && f1 == mine_fb ? 1 : 0) + ((sub & 2) && f2 == mine_fb ? 1 : 0) +
-                                             (sub >= 2 && f3 == mine_fb ? 1 : 0);
+                            const int turn = turn_among_lower_lanes(pending ? fb : kTurnIdle, sub, (int)maxn);
                             T *grow = G + (size_t)row[j] * COUT;
+                            if (CONV3P_SP_ABLATE & 256) {          // developer timing: no read-modify-write at all
+                                if (pending) {
 #pragma unroll
-                            for (int p = 0; p < 4; ++p) {
+                                    for (int c = 0; c < COUT; ++c) asm volatile("" :: "v"(v[c]));
+                                }
+                            } else if (CONV3P_SP_ABLATE & 512) {   // developer timing: one (racy) round whatever the taps
+                                if (pending) {
+#pragma unroll
+                                    for (int c = 0; c < COUT; ++c) grow[c] += v[c];
+                                }
+                            } else
+                            for (int p = 0; p < (int)maxn; ++p) {
                                 if (p > 0 && !__any(pending && turn >= p)) break;
                                 if (pending && turn == p) {
 #pragma unroll
@@ -325,34 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                             }
                         }
-#else
-                        // sub-lanes of one centre that meet on a tap: the lower one absorbs the higher (fixed order)
-#pragma unroll
-                        for (int step = 0; step < 3; ++step) {
-                            const uint32_t mine_fb = pending ? fb : kNoTap;
-                            uint32_t pfb;
-                            bool lower;
-                            if (step == 0) { pfb = lane_xor16(mine_fb); lower = (sub & 1) == 0; }
-                            else if (step == 1) { pfb = lane_xor32(mine_fb); lower = sub < 2; }
-                            else { pfb = lane_xor32(lane_xor16(mine_fb)); lower = sub < 2; }
-                            const bool same = pending && pfb == fb;
-                            if (__any(same)) {
-#pragma unroll
-                                for (int c = 0; c < COUT; ++c) {
-                                    const T pv = step == 0 ? lane_xor16(v[c])
-                                               : step == 1 ? lane_xor32(v[c]) : lane_xor32(lane_xor16(v[c]));
-                                    if (same && lower) v[c] += pv;
-                                }
-                                if (same && !lower) pending = false;
-                            }
-                        }
-                        if (pending) {
-                            T *grow = G + (size_t)row[j] * COUT;
-#pragma unroll
-                            for (int c = 0; c < COUT; ++c) grow[c] += v[c];
-                        }
-#endif
-                        i += 4;
+                        i += wk.step;
                     }
                 }
             }
@@ -478,16 +482,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
         }
     };
     T dx[CIN];
+    SDBG()
     if (nrounds == 1) {
         // the common case (every tile of the models' strides >= 2): nothing but phase A's own state is live across it
         zero_G(st.ntap);
         __syncthreads();
+        SDBG()
         phase_A(0, st.ntap);
+        SDBG()
         __syncthreads();
+        SDBG()
         phase_B(0, st.ntap);
+        SDBG()
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
         phase_C(0, st.ntap, dx);
+        SDBG()
     } else {
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
@@ -519,6 +529,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
             grad_input[rr * ld.dx + k] = sum;
         }
     }
+#if CONV3P_SP_ABLATE & 128
+    SDBG()
+    if (lane == 0 && nrounds == 1 && (blockIdx.x % 211) == 7)   // developer instrumentation build only (10 ns ticks)
+        printf("bsp<%d,%d> wg %d wave %d: prologue %lld  zero+sync %lld  phaseA %lld  sync %lld  B %lld  C %lld  reduce+store %lld\n", CIN, COUT,
+               (int)blockIdx.x, wave, st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], st_[7] - st_[6]);
+#endif
 }
 
 }  // namespace conv3p

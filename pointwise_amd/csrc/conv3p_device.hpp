@@ -509,6 +509,151 @@ __device__ __forceinline__ int wave_excl_scan(int v, int &total)
     return inc - v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lanes of a wave dealt to its 16 centres IN PROPORTION TO THEIR PAIR LISTS (round 5).  The list-walking kernels gave
+// every centre four lanes that stepped through its list four records at a time until the longest of the wave's 16
+// lists was consumed: steps = ceil(max len / 4), 59-75 % of the lane-steps on a record (profiles/r05_walk_stats.txt).
+// Here centre c gets n_c = ceil(len_c / S) consecutive lanes, S the smallest step count for which the 16 centres fit
+// the 64 lanes; lane r of a centre takes the records r, r + n_c, r + 2 n_c, ...: steps = S ~ ceil(sum len / 56).
+// A lane keeps its centre for the whole walk, so accumulators stay in registers and the lanes of a centre (consecutive:
+// [first, first + n)) are combined once, at the end, in ascending lane order -- bitwise reproducible.
+//   seg      (start, length) of the list of centre (lane & 15) of this wave, the same in the four 16-lane rows
+//   scratch  112 words of LDS private to the wave
+// Returns the lane's centre (0 .. 15 within the wave), its index among the centre's lanes, their number (0: idle
+// lane) and the centre's own segment; `spans[c]` = first lane | lanes << 8 of every centre is left in scratch[64 + c].
+struct LaneShare {
+    uint32_t cl, r, n;
+    uint2 seg;
+    uint32_t maxn;   // the largest lane count of a centre of this wave (uniform)
+};
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v)   // sum over the 16 lanes of a row, in every lane
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);   // row_ror:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);   // row_ror:1
+    return v;
+}
+__device__ __forceinline__ uint32_t row16_incl_scan(uint32_t v)   // inclusive prefix sum inside a 16-lane row
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1 (zeros shifted in)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    return v;
+}
+__device__ __forceinline__ uint32_t ceil_div_small(uint32_t a, uint32_t s, float rs)   // ceil(a / s), a + s < 2^23, rs = 1 / s
+{
+    const uint32_t x = a + s - 1u;
+    uint32_t q = (uint32_t)((float)x * rs);   // within one of floor(x / s)
+    q = q * s > x ? q - 1u : q;
+    q = (q + 1u) * s <= x ? q + 1u : q;
+    return q;
+}
+constexpr int kShareWords = 112;   // LDS words share_lanes() needs per wave: heads [64] | spans [16] | segments [16][2]
+__device__ __forceinline__ LaneShare share_lanes(uint2 seg, uint32_t *scratch)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t len = seg.y == 0xFFFFFFFFu ? 0u : seg.y;   // (an overflowed tile never gets here)
+    const uint32_t tot = row16_sum(len);
+    // expected demand at S steps: sum len / S + half a lane per centre -> start at sum / 56; every further S is tried
+    // in turn (sum / 48 always fits: sum ceil(len / S) <= sum / S + 16)
+    uint32_t S = tot / 56u + 1u;
+    uint32_t q;
+    for (;;) {
+        q = ceil_div_small(len, S, 1.0f / (float)S);
+        if (__builtin_amdgcn_readfirstlane((int)row16_sum(q)) <= 64) break;
+        ++S;
+    }
+    const uint32_t first = row16_incl_scan(q) - q;
+    uint32_t qmax = q;
+    qmax = max(qmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qmax, 0x128, 0xF, 0xF, false));   // row_ror:8
+    qmax = max(qmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qmax, 0x124, 0xF, 0xF, false));
+    qmax = max(qmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qmax, 0x122, 0xF, 0xF, false));
+    qmax = max(qmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qmax, 0x121, 0xF, 0xF, false));
+    scratch[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16u) {
+        if (q != 0u) scratch[first] = lane + 1u;
+        scratch[64 + lane] = first | (q << 8);
+        scratch[80 + 2 * lane] = seg.x;
+        scratch[81 + 2 * lane] = seg.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t heads = __ballot(scratch[lane] != 0u);
+    const uint64_t below = heads & (~0ull >> (63u - lane));   // heads at or below this lane
+    LaneShare ls;
+    ls.maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)qmax);
+    if (below == 0ull) {
+        ls.cl = 0u; ls.r = 0u; ls.n = 0u;
+        ls.seg = make_uint2(0u, 0u);
+        return ls;
+    }
+    const uint32_t h = 63u - (uint32_t)__builtin_clzll(below);
+    ls.cl = scratch[h] - 1u;
+    const uint32_t span = scratch[64 + ls.cl];
+    ls.r = lane - h;
+    ls.n = span >> 8;
+    ls.seg = make_uint2(scratch[80 + 2 * ls.cl], scratch[81 + 2 * ls.cl]);
+    if (ls.r >= ls.n) {   // lanes past the last centre's share
+        ls.n = 0u;
+        ls.seg.y = 0u;
+    }
+    return ls;
+}
+// A lane's walk over its share of its centre's list: records i, i + step, ... below end.
+//   interleaved (forward: nothing is shared between the lanes of a centre): lane r takes r, r + n, r + 2 n, ...
+//   blocked (backward: lanes of a centre that meet on a tap take turns, and neighbours in a list -- neighbours in
+//   space -- mostly share their tap): lane r takes the r-th run of ceil(len / n) consecutive records
+struct LaneWalk {
+    uint32_t i, step, end;
+};
+__device__ __forceinline__ LaneWalk lane_walk(const LaneShare &ls, bool blocked)
+{
+    LaneWalk w;
+    if (ls.n == 0u) {
+        w.i = 0u; w.step = 1u; w.end = 0u;
+    } else if (blocked) {
+        const uint32_t per = ceil_div_small(ls.seg.y, ls.n, 1.0f / (float)ls.n);
+        w.i = ls.r * per;
+        w.step = 1u;
+        w.end = w.i + per < ls.seg.y ? w.i + per : ls.seg.y;
+        if (w.i > w.end) w.i = w.end;
+    } else {
+        w.i = ls.r;
+        w.step = ls.n;
+        w.end = ls.seg.y;
+    }
+    return w;
+}
+// Turn of this lane among the lanes of its centre (the r lanes just below it belong to the same centre) that want the
+// same tap in this step: the number of those lower lanes whose tap equals this lane's.  `tap` = kTurnIdle for a lane
+// that wants nothing; maxn = the largest lane count of a centre in this wave (uniform).
+constexpr uint32_t kTurnIdle = 0xFFFFFFFFu;
+__device__ __forceinline__ int turn_among_lower_lanes(uint32_t tap, uint32_t r, int maxn)
+{
+    int turn = 0;
+    uint32_t t = tap;
+    for (int d = 1; d < maxn; ++d) {
+        t = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)t, 0x138, 0xF, 0xF, false);   // wave_shr:1: lane l <- lane l - 1
+        turn += ((uint32_t)d <= r && t == tap && tap != kTurnIdle) ? 1 : 0;
+    }
+    return turn;
+}
+// the same interface with four consecutive lanes per centre (clouds searched in several groups: a lane must keep its
+// centre from one group's list to the next)
+__device__ __forceinline__ LaneShare share_lanes_uniform(uint2 seg_of_my_centre)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    LaneShare ls;
+    ls.cl = lane >> 2;
+    ls.r = lane & 3u;
+    ls.n = 4u;
+    ls.seg = seg_of_my_centre;
+    ls.maxn = 4u;
+    return ls;
+}
+
 // Per-centre exact data kept in LDS for the dense (lane = pair) stages.
 template <typename T> struct CentreRec {
     T p[3];

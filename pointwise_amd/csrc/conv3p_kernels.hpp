@@ -768,6 +768,27 @@ __device__ __forceinline__ bool block_to_tile(const BlockMap &m, const uint32_t 
     return true;
 }
 
+// LDS layout of the forward kernel's filter copy (register path).  fp32: a tap's block is [Cin][Cout rounded up to
+// even], so that a lane reads two consecutive output channels' weights with ONE aligned 8-byte access (ds_read_b64:
+// 256 B / clk against 128 for 4-byte reads -- the walk's 81 weight reads per record were 80 % of the LDS's cycles and
+// the LDS was what bounded the loop, profiles/r05_cfg2_pmc.txt) feeding one v_pk_fma_f32; the tap stride is a multiple
+// of 2 words whose half is odd, so lanes on different taps spread over all 32 bank pairs.  fp64: [Cin][Cout], odd stride.
+template <typename T> __host__ __device__ constexpr int fwd_coutp(int cout) { return sizeof(T) == 4 ? ((cout + 1) & ~1) : cout; }
+template <typename T> __host__ __device__ constexpr int fwd_wstr(int cin, int cout)
+{
+    if (sizeof(T) != 4) return (cin * cout) | 1;
+    const int w = cin * fwd_coutp<T>(cout);
+    return (w / 2) % 2 == 0 ? w + 2 : w;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef CONV3P_BWD_BLOCKED
+#define CONV3P_BWD_BLOCKED 1   // developer A/B: 0 = the lanes of a centre take its records interleaved (1: one run each)
+#endif
+// one aligned 8-byte LDS read that hipcc will not pair with its neighbour into ds_read2_b64 (which runs at the 4-byte
+// reads' 128 B / clk, MI355X_MICROARCH.md, LDS table): a volatile access in the LDS address space
+typedef __attribute__((address_space(3))) const volatile f32x2 lds_cv_f32x2;
+__device__ __forceinline__ f32x2 lds_read_b64(const float *p) { return *(lds_cv_f32x2 *)p; }
+
 // ---------------------------------------------------------------------------------
 // forward accumulate: out[i,c] = sum over pairs of W[f,k,c] * x[j,k] / count[i,f]  (.cpp:480-494)
 // One workgroup = one query tile; threads stride over the tile's pair segment (lane = pair).
@@ -802,7 +823,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     const size_t nw = (size_t)st.ntap * cin * cout;
     // LDS stride of one tap's [Cin][Cout] block: odd, so that lanes working on different taps spread over all the
     // banks (36 x 13 = 468 = 20 mod 32 would put every tap on one of 8 banks: the 36 -> 13 layer ran 2x slower)
-    constexpr int WSTR = kSmall ? ((CIN * COUT) | 1) : 1;
+    constexpr int COUTP = kSmall ? fwd_coutp<T>(COUT) : 1;              // row of one input channel (fp32: padded to even)
+    constexpr int WSTR = kSmall ? fwd_wstr<T>(CIN, COUT) : 1;
+    constexpr bool kPk = kSmall && sizeof(T) == 4;                     // fp32 register path: 8-byte weight reads, packed FMAs
     if (kSmall) off += align16((size_t)st.ntap * WSTR * sizeof(T));
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);   // populations of the tile's centres [tap][65] ...
     T *rcpt = reinterpret_cast<T *>(smem + off);                // ... or (dense small path) their reciprocals 1/(T)count
@@ -813,7 +836,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
     T *red = reinterpret_cast<T *>(smem + off);   // [4][COUT][64], overflow path only
-    const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense path: centre and sub-lane of this thread
+    int cq = wave * 16 + (lane >> 2);   // dense path: this lane's centre (re-dealt below, share_lanes)
+    uint32_t sub = lane & 3u, nsub = 4u;   //   ... its index among the centre's lanes, and their number
+    uint32_t *share = reinterpret_cast<uint32_t *>(soa);   // the wave's lane-sharing scratch (soa is the overflow path's)
 
     int b, qt;
     if (!block_to_tile(bm, sched, ntiles, b, qt)) return;   // uniform
@@ -850,8 +875,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (e0 + u * 256 < (uint32_t)nw) {
-                    const uint32_t e = e0 + u * 256, f = e / (CIN * COUT);
-                    w_lds[f * WSTR + (e - f * (CIN * COUT))] = v[u];
+                    const uint32_t e = e0 + u * 256, f = e / (CIN * COUT), kc = e - f * (CIN * COUT);
+                    const uint32_t k = kc / COUT, c = kc - k * COUT;
+                    w_lds[f * WSTR + k * COUTP + c] = v[u];
+                    if (COUTP != COUT && c == COUT - 1) w_lds[f * WSTR + k * COUTP + COUT] = (T)0;   // the padding column
                 }
         }
     }
@@ -874,18 +901,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     uint2 sg = make_uint2(0u, 0u);
     const PairEntry *pe = pairs;
     const T *in_cloud = input + (size_t)b * N * ld.in;
+    // Lanes dealt to the wave's 16 centres in proportion to their lists (share_lanes, conv3p_device.hpp) when the cloud
+    // was searched in one group; else four consecutive lanes per centre (a lane keeps its centre across the groups).
+    const bool shared = kSmall && ngroups == 1;
     auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
     auto ld_row = [&](int sl, uint32_t i) {
         const bool ok = i < sg.y && code_fwd(rec[sl].code) != kNoTap;
         RowLoader<T, CINR>::load(in_cloud + (size_t)(ok ? ((CONV3P_ABLATE & 1024) ? (rec[sl].cand & 63u) : rec[sl].cand) : 0u) * ld.in, xs[sl]);   // (1024: developer, every gather an L1 hit)
     };
     auto start_group = [&](int g) {
-        sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
+        if (shared) {
+            const LaneShare ls = share_lanes(qsegs[tile_id * 64 + wave * 16 + (lane & 15)], share);
+            cq = wave * 16 + (int)ls.cl;
+            sub = ls.r;
+            nsub = ls.n;
+            sg = ls.seg;
+        } else {
+            sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
+            if (lane < 16) share[64 + lane] = (uint32_t)(4 * lane) | (4u << 8);   // the centres' lane spans, as share_lanes leaves them
+        }
         pe = pairs + sg.x;
 #pragma unroll
-        for (int sl = 0; sl < NS - 1; ++sl) rec[sl] = ld_rec(sub + 4 * sl);
+        for (int sl = 0; sl < NS - 1; ++sl) rec[sl] = ld_rec(sub + nsub * sl);
 #pragma unroll
-        for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + 4 * sl);
+        for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + nsub * sl);
     };
     if (kSmall && !overflow) start_group(0);
     FDBG()
@@ -918,10 +957,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 
     FDBG()
     T *out_cloud = output + (size_t)b * N * ld.out;
-    T acc[kSmall ? COUT : 1];
+    T acc[kSmall ? COUTP : 1];
     if (kSmall) {
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = (T)0;
+        for (int c = 0; c < COUTP; ++c) acc[c] = (T)0;
     }
     // centre = lane `ql` (always this lane on the small path)
     auto accumulate = [&](uint32_t cand, uint32_t f, uint32_t ql, T rcp) {
@@ -936,7 +975,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 #pragma unroll
             for (int k = 0; k < CIN; ++k)
 #pragma unroll
-                for (int c = 0; c < COUT; ++c) acc[c] = fma_t(wf[k * COUT + c], xs[k], acc[c]);
+                for (int c = 0; c < COUT; ++c) acc[c] = fma_t(wf[k * COUTP + c], xs[k], acc[c]);
         } else {
             const T *wf = filter + (size_t)f * cin * cout;
             T *orow = out_cloud + (size_t)qorig[ql] * ld.out;
@@ -972,21 +1011,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                             more = false;
                             break;
                         }
-                        rec[(j + NS - 1) % NS] = ld_rec(i + 4 * (NS - 1));
-                        ld_row((j + NS - 2) % NS, i + 4 * (NS - 2));
+                        rec[(j + NS - 1) % NS] = ld_rec(i + nsub * (NS - 1));
+                        ld_row((j + NS - 2) % NS, i + nsub * (NS - 2));
                         __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of this step's arithmetic
                         const uint32_t f = code_fwd(rec[j].code);
                         if (i < sg.y && f != kNoTap) {
                             const T rcp = rcpt[f * kCntStride + cq];
                             const T *wf = w_lds + (size_t)f * WSTR;
+                            if constexpr (kPk) {
+                                // two output channels per LDS access and per FMA instruction: the same products and
+                                // sums, in the same order per channel, as the scalar form below
+                                // (the weights of input channel k + 1 are requested before channel k's products:
+                                // the volatile reads issue in source order)
+                                f32x2 wq[2][COUTP / 2];
+#pragma unroll
+                                for (int c2 = 0; c2 < COUTP / 2; ++c2) wq[0][c2] = lds_read_b64(wf + 2 * c2);
+#pragma unroll
+                                for (int k = 0; k < CIN; ++k) {
+                                    if (k + 1 < CIN) {
+#pragma unroll
+                                        for (int c2 = 0; c2 < COUTP / 2; ++c2) wq[(k + 1) & 1][c2] = lds_read_b64(wf + (k + 1) * COUTP + 2 * c2);
+                                    }
+                                    const float xk = xs[j][k] * rcp;              // x / count, .cpp:492
+                                    const f32x2 xk2 = {xk, xk};
+#pragma unroll
+                                    for (int c2 = 0; c2 < COUTP / 2; ++c2) {
+                                        f32x2 a = {acc[2 * c2], acc[2 * c2 + 1]};
+                                        a = __builtin_elementwise_fma(wq[k & 1][c2], xk2, a);
+                                        acc[2 * c2] = a.x;
+                                        acc[2 * c2 + 1] = a.y;
+                                    }
+                                }
+                            } else {
 #pragma unroll
                             for (int k = 0; k < CIN; ++k) {
                                 const T xk = xs[j][k] * rcp;                  // x / count, .cpp:492
 #pragma unroll
-                                for (int c = 0; c < COUT; ++c) acc[c] = fma_t(wf[k * COUT + c], xk, acc[c]);
+                                for (int c = 0; c < COUT; ++c) acc[c] = fma_t(wf[k * COUTP + c], xk, acc[c]);
+                            }
                             }
                         }
-                        i += 4;
+                        i += nsub;
 #if CONV3P_ABLATE & 134217728
                         fsteps++;
 #endif
@@ -1018,15 +1083,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 
     if constexpr (kSmall) {
         if (!overflow) {
-            // the 4 sub-lanes of a centre hold partial rows: fixed-order butterfly, lane `cq & 15` of
-            // sub-lane 0 writes the row
-            const int orig = qorig[cq];
+            // the lanes of a centre (consecutive, spans in share[64 + centre]) hold partial rows: staged in the wave's part
+            // of `red` and summed in ascending lane order by thread (centre, channel), which also stores the value --
+            // consecutive lanes write consecutive channels of a row
+            T *rw = red + (size_t)wave * COUT * 64;
 #pragma unroll
-            for (int c = 0; c < COUT; ++c) {
-                T v = acc[c];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                if (sub == 0 && orig >= 0) out_cloud[(size_t)orig * ld.out + c] = act ? selu_value(v) : v;
+            for (int c = 0; c < COUT; ++c) rw[c * 64 + lane] = acc[c];
+            __builtin_amdgcn_wave_barrier();
+            for (int o = lane; o < 16 * COUT; o += 64) {
+                const int ci = o / COUT, ch = o - ci * COUT;
+                const uint32_t span = share[64 + ci];
+                const T *src = rw + ch * 64 + (span & 255u);
+                const int cnt_l = (int)(span >> 8);
+                T v = (T)0;
+                for (int jj = 0; jj < cnt_l; ++jj) v += src[jj];
+                const int orig = qorig[wave * 16 + ci];
+                if (orig >= 0) out_cloud[(size_t)orig * ld.out + ch] = act ? selu_value(v) : v;
             }
 #if CONV3P_ABLATE & 134217728
             FDBG()
@@ -1106,7 +1178,8 @@ __global__ __launch_bounds__(256) void backward_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
-    const int cq = wave * 16 + (lane & 15), sub = lane >> 4;   // dense phase A: centre and sub-lane
+    int cq = wave * 16 + (lane >> 2);      // dense phase A: this lane's centre (re-dealt there, share_lanes), ...
+    uint32_t sub = lane & 3u, maxn = 4u;   //   its index among the centre's lanes, the largest lane count of a centre
 
 #if CONV3P_ABLATE & 33554432
     long long bt[8];
@@ -1210,13 +1283,24 @@ __global__ __launch_bounds__(256) void backward_kernel(
             for (int g = 0; g < ngroups; ++g) {
                 if constexpr (kSmall) {
                     if (CONV3P_ABLATE & 1) continue;
-                    // wave w owns the centres 16w..16w+15; lanes {c, c+16, c+32, c+48} walk centre c's list
-                    // 4 records per step.  Two sub-lanes of a centre may hit the same tap in one step: the
-                    // lower sub-lane goes first (fixed order), the other retries -> race-free, reproducible.
-                    const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cq];
+                    // wave w owns the centres 16w..16w+15; its lanes are dealt to them in proportion to their lists
+                    // (share_lanes; four consecutive lanes per centre when the cloud was searched in several groups)
+                    // and every lane walks its own run of its centre's list.  Lanes of a centre that hit the same tap
+                    // in one step take turns, lower lane first (fixed order) -> race-free, reproducible.
+                    LaneShare ls;
+                    if (ngroups == 1) {
+                        ls = share_lanes(qsegs[tile_id * 64 + wave * 16 + (lane & 15)], reinterpret_cast<uint32_t *>(soa));
+                        cq = wave * 16 + (int)ls.cl;
+                        sub = ls.r;
+                        maxn = ls.maxn;
+                    } else {
+                        ls = share_lanes_uniform(qsegs[(tile_id * ngroups + g) * 64 + cq]);
+                    }
+                    const uint2 sg = ls.seg;
+                    const LaneWalk wk = lane_walk(ls, CONV3P_BWD_BLOCKED != 0);
                     const PairEntry *pe = pairs + sg.x;
                     auto live_rec = [&](const PairEntry &r, uint32_t i) {
-                        return i < sg.y && code_fwd(r.code) != kNoTap && code_bwd(r.code) != kNoTap;
+                        return i < wk.end && code_fwd(r.code) != kNoTap && code_bwd(r.code) != kNoTap;
                     };
                     auto cnt_of = [&](const PairEntry &r, bool live) {
                         if (CONV3P_ABLATE & 2048) return 1;   // developer: timing without the gather
@@ -1232,9 +1316,6 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     // registers; the record of step k+kDepth-1 and the dY row + population of step k+kDepth-2 are in
                     // flight while step k runs.  (Rotating slots by register copies made every step wait for the
                     // newest load -- a copy reads its destination -- so that "pipeline" drained the queue every step.)
-#ifndef CONV3P_BWD_TURNS
-#define CONV3P_BWD_TURNS 1   // developer A/B: 0 = equal-tap sub-lanes merged by lane swaps before one read-modify-write
-#endif
 #ifndef CONV3P_BWD_DEPTH
 #define CONV3P_BWD_DEPTH 4
 #endif
@@ -1243,29 +1324,29 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     bool lv[kDepth];
                     int cn[kDepth];
                     T val[kDepth][COUT];
-                    auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
+                    auto ld_rec = [&](uint32_t i) { return pe[i < wk.end ? i : 0u]; };
                     auto gather = [&](int sl, uint32_t i) {
                         lv[sl] = live_rec(rec[sl], i);
                         cn[sl] = cnt_of(rec[sl], lv[sl]);
                         RowLoader<T, COUT>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy, val[sl]);
                     };
 #pragma unroll
-                    for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = ld_rec(sub + 4 * sl);
+                    for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = ld_rec(wk.i + wk.step * sl);
                     __builtin_amdgcn_sched_barrier(0);   // the records are the oldest loads in flight on entry
 #pragma unroll
-                    for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, sub + 4 * sl);
+                    for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, wk.i + wk.step * sl);
                     T ablate_sink = (T)0;
-                    uint32_t i = sub;
+                    uint32_t i = wk.i;
                     bool more = true;
                     while (more) {
 #pragma unroll
                         for (int j = 0; j < kDepth; ++j) {
-                            if (!__any(i < sg.y)) {
+                            if (!__any(i < wk.end)) {
                                 more = false;
                                 break;
                             }
-                            rec[(j + kDepth - 1) % kDepth] = ld_rec(i + 4 * (kDepth - 1));
-                            gather((j + kDepth - 2) % kDepth, i + 4 * (kDepth - 2));
+                            rec[(j + kDepth - 1) % kDepth] = ld_rec(i + wk.step * (kDepth - 1));
+                            gather((j + kDepth - 2) % kDepth, i + wk.step * (kDepth - 2));
                             __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of this step's arithmetic
                             // false positive, hole, or empty tap (.cpp:679) -> contributes nothing
                             bool pending = lv[j] & (cn[j] != 0);
@@ -1293,20 +1374,15 @@ __global__ __launch_bounds__(256) void backward_kernel(
                                 }
                                 pending = false;
                             }
-#if CONV3P_BWD_TURNS
-                            // Sub-lanes of one centre that target the same tap take TURNS at the tap's G entries, lower
-                            // sub-lane first: turn = number of lower sub-lanes with the same tap (three swaps of the tap
-                            // alone); a wave's LDS accesses execute in program order, so turn p adds to what turn p - 1
-                            // wrote -- race-free and in a fixed order.  (Until round 3 the lower lane absorbed the higher
-                            // one's values through lane swaps first: 40 swaps and 75 selects per step.)
+                            // Lanes of one centre that target the same tap take TURNS at the tap's G entries, lower lane
+                            // first: turn = number of lower lanes of the centre with the same tap; a wave's LDS accesses
+                            // execute in program order, so turn p adds to what turn p - 1 wrote -- race-free and in a fixed
+                            // order.  (Until round 3 the lower lane absorbed the higher one's values through lane swaps
+                            // first: 40 swaps and 75 selects per step.)
                             {
-                                const uint32_t mine_fb = pending ? fb : kNoTap;
-                                const uint32_t f1 = lane_xor16(mine_fb), f2 = lane_xor32(mine_fb), f3 = lane_xor32(f1);
-                                const int turn = ((sub & 1) && f1 == mine_fb ? 1 : 0) + ((sub & 2) && f2 == mine_fb ? 1 : 0) +
-                                                 (sub >= 2 && f3 == mine_fb ? 1 : 0);
+                                const int turn = turn_among_lower_lanes(pending ? fb : kTurnIdle, sub, (int)maxn);
                                 T *grow = G + ((size_t)(pending ? fb : 0u) * COUT) * kCntStride + cq;
-#pragma unroll
-                                for (int p = 0; p < 4; ++p) {
+                                for (int p = 0; p < (int)maxn; ++p) {
                                     if (p > 0 && !__any(pending && turn >= p)) break;
                                     if (pending && turn == p) {
 #pragma unroll
@@ -1315,37 +1391,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                 }
                             }
-#else
-                            // Sub-lanes of one centre that target the same tap are merged first (fixed order:
-                            // partner distance 16, 32, 48 lanes; the lower sub-lane absorbs the higher one), so a
-                            // single race-free read-modify-write round follows.  Neighbouring candidates usually
-                            // share a tap, so without the merge this would take 2-3 rounds.
-#pragma unroll
-                            for (int step = 0; step < 3; ++step) {
-                                const uint32_t mine_fb = pending ? fb : kNoTap;
-                                uint32_t pfb;
-                                bool lower;
-                                if (step == 0) { pfb = lane_xor16(mine_fb); lower = (sub & 1) == 0; }
-                                else if (step == 1) { pfb = lane_xor32(mine_fb); lower = sub < 2; }
-                                else { pfb = lane_xor32(lane_xor16(mine_fb)); lower = sub < 2; }
-                                const bool same = pending && pfb == fb;
-                                if (__any(same)) {
-#pragma unroll
-                                    for (int c = 0; c < COUT; ++c) {
-                                        const T pv = step == 0 ? lane_xor16(v[c])
-                                                   : step == 1 ? lane_xor32(v[c]) : lane_xor32(lane_xor16(v[c]));
-                                        if (same && lower) v[c] += pv;
-                                    }
-                                    if (same && !lower) pending = false;
-                                }
-                            }
-                            if (pending) {
-                                T *grow = G + ((size_t)fb * COUT) * kCntStride + cq;
-#pragma unroll
-                                for (int c = 0; c < COUT; ++c) grow[c * kCntStride] += v[c];
-                            }
-#endif
-                            i += 4;
+                            i += wk.step;
                         }
                     }
                     if (CONV3P_ABLATE & 256) G[cq] += ablate_sink;

@@ -37,7 +37,7 @@ constexpr int kFHeader = 3 * kFEntries;        // u64 index of the header: {tmin
 constexpr int kFTableU64 = kFHeader + 4;       // 352 x 8 B = 2816 B = 176 x 16 B
 constexpr int kFMaxExt = 8;                    // taps per axis the look-up loops take
 #ifndef CONV3P_DEV_FUSED_ABLATE
-#define CONV3P_DEV_FUSED_ABLATE 0   // developer timing builds (wrong results): 1 no exact stage, 2 no pass 2, 4 empty masks, 8 no epilogue
+#define CONV3P_DEV_FUSED_ABLATE 0   // developer timing builds (wrong results unless 16): 1 no exact stage, 2 no pass 2, 4 empty masks, 8 no epilogue, 16 no compaction (correct)
 #endif
 constexpr int kFStream = 192;                  // entries of a wave's pair stream (drained 128 at a time, < 64 carried over)
 constexpr int kFMaxE = 12;                     // coarsest table (buckets of 2^12 / 16 voxels); beyond: everything is a candidate
@@ -483,7 +483,9 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         }
         base = __shfl(base, 0);
         ok = __shfl(ok, 0);
-        job.qsegs[((size_t)b * ntiles + qt) * ngroups * 64 + lane] = ok ? make_uint2(base + offq, nq) : make_uint2(0u, kSegOverflow);
+        // (a tile whose reservation held gets its per-centre segments after pass 2, with the false positives squeezed out)
+        if (!ok || (CONV3P_DEV_FUSED_ABLATE & 16))
+            job.qsegs[((size_t)b * ntiles + qt) * ngroups * 64 + lane] = ok ? make_uint2(base + offq, nq) : make_uint2(0u, kSegOverflow);
         for (int g = 1; g < ngroups; ++g) job.qsegs[(((size_t)b * ntiles + qt) * ngroups + g) * 64 + lane] = make_uint2(0u, 0u);
         }
         nqw[lane] = offq;
@@ -568,6 +570,77 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         if (have > 0) drain(have);
     }
     __syncthreads();
+
+    // ---- compaction (round 5).  The tables are a superset filter: on the models' dilated stencils a third of the
+    //      pre-filter hits are false positives (window of 18 buckets where 16 decide, on three axes), stored above as
+    //      kNoTap records that every list-walking kernel then steps over -- a third of the forward's and backward's steps.
+    //      Here every centre's list is squeezed to its live records (forward tap present), order kept, in place: wave w
+    //      takes the contiguous run of the centres 16w .. 16w + 15, lane = record, 64 at a time; a live record's place
+    //      in its centre's list is the number of live records of the same centre before it (one ballot; the centre's
+    //      first lane in the chunk from its slot offset; a count carried over when a list straddles two chunks).  A
+    //      record only ever moves DOWN inside its own centre's slots, so nothing unread is overwritten; the slots past
+    //      the live records are rewritten as kNoTap records (tile-level readers of `segs` see no duplicates).  The live
+    //      count of a centre is the sum of its populations, already in LDS.
+    if (have_pairs && ok && !(CONV3P_DEV_FUSED_ABLATE & 16)) {
+        uint32_t *livec = nqw + 64;   // [64]; entry c is written and read by the wave that owns centre c only
+        {
+            const int c = wave * 16 + (lane & 15);
+            uint32_t sacc = 0;
+            for (int f = lane >> 4; f < st.ntap; f += 4) sacc += cnt[f * kCntStride + c];
+            sacc += lane_xor16(sacc);
+            sacc += lane_xor32(sacc);
+            if (lane < 16) livec[c] = sacc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t r0 = nqw[wave * 16], r1 = wave == kWavesPerBlock - 1 ? misc[2] : nqw[wave * 16 + 16];
+        PairEntry *tp = job.pairs + gbase;
+        const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        uint32_t carry = 0;
+        // kCB chunks of 64 records per batch, the next batch requested before this one is worked on: the run of a wave
+        // (~530 records on the cfg2 clouds) costs two or three memory round trips instead of one per chunk (first
+        // version, one chunk ahead: +22 us on the 98-us search of the cfg2 step)
+        constexpr int kCB = 4;
+        PairEntry cur[kCB], nxt[kCB];
+        auto request = [&](PairEntry (&dst)[kCB], uint32_t pos) {
+#pragma unroll
+            for (int u = 0; u < kCB; ++u) {
+                const uint32_t i = pos + (uint32_t)(u * 64 + lane);
+                dst[u] = tp[i < r1 ? i : r0];
+            }
+        };
+        if (r0 < r1) request(nxt, r0);   // (uniform)
+        for (uint32_t pos = r0; pos < r1; pos += 64 * kCB) {
+#pragma unroll
+            for (int u = 0; u < kCB; ++u) cur[u] = nxt[u];
+            if (pos + 64 * kCB < r1) request(nxt, pos + 64 * kCB);   // (its slots lie above everything this batch stores to)
+#pragma unroll
+            for (int u = 0; u < kCB; ++u) {
+                const uint32_t cpos = pos + (uint32_t)(u * 64);
+                if (cpos >= r1) break;   // (uniform)
+                const uint32_t i = cpos + (uint32_t)lane;
+                const bool valid = i < r1;
+                const uint32_t c = code_q(cur[u].code) & 63u;
+                const bool live = valid && code_fwd(cur[u].code) != kNoTap;
+                const uint32_t oc = nqw[c], lv = livec[c];
+                const uint64_t Lm = __ballot(live);
+                const uint32_t sc = oc > cpos ? oc - cpos : 0u;   // first lane of centre c in this chunk (<= lane)
+                const uint64_t before = Lm & lt & ~((1ull << (sc & 63u)) - 1ull);
+                const uint32_t rank = (uint32_t)__popcll(before) + (oc < cpos ? carry : 0u);
+                if (live && oc + rank != i) tp[oc + rank] = cur[u];
+                if (valid && i - oc >= lv) {
+                    PairEntry dead;
+                    dead.cand = cur[u].cand;
+                    dead.code = pair_code(kNoTap, kNoTap, c);
+                    tp[i] = dead;
+                }
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)(rank + (live ? 1u : 0u)), 63);
+            }
+        }
+        if (lane < 16) {
+            const int c = wave * 16 + lane;
+            job.qsegs[((size_t)b * ntiles + qt) * ngroups * 64 + c] = make_uint2(gbase + nqw[c], livec[c]);
+        }
+    }
 
     // ---- epilogue: populations in both layouts, backward-tap sets, slot commit.  Thread (wave w, lane q) serves
     //      centre q (its record is still in the thread's registers).
