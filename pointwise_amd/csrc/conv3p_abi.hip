@@ -439,10 +439,16 @@ template <typename T> int run_prep(const T *points, const Call<T> &c)
         while (npad < d.N) npad <<= 1;
         const int threads = npad / 2 < 1024 ? (npad / 2 < 64 ? 64 : npad / 2) : 1024;
         const size_t lds = (size_t)npad * 8 + 256;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(prep_sort_kernel<T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(prep_sort_kernel<T>, dim3(d.B), dim3(threads), lds, c.s, points, d.N, d.ntiles, npad,
-                           c.L.pts, c.L.boxes, c.cc);
+        auto launch = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(d.B), dim3(threads), lds, c.s, points, d.N, d.ntiles, npad, c.L.pts, c.L.boxes, c.cc);
+        };
+        switch (npad / threads) {   // keys per thread
+        case 2: launch(prep_sort_kernel<T, 2>); break;
+        case 4: launch(prep_sort_kernel<T, 4>); break;
+        case 8: launch(prep_sort_kernel<T, 8>); break;
+        default: launch(prep_sort_kernel<T, 16>); break;
+        }
         return hip_ok();
     }
     dim3 grid((d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock, d.B);

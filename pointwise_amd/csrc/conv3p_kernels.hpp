@@ -174,33 +174,64 @@ __device__ __forceinline__ uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z
     return (spread10(X[0] ^ t) << 2) | (spread10(X[1] ^ t) << 1) | spread10(X[2] ^ t);
 }
 
-template <typename T>
+// Round 5: the keys are 32-bit -- the top cb bits of the Hilbert index (cb = the largest multiple of 3 that leaves room
+// for the point's index: 21 bits = 7 per axis at N <= 2048, 18 above; the curve is hierarchical, so its leading bits are
+// the index of the coarser cell) over the index -- and live in REGISTERS, KPT per thread (element e = s * threads + t):
+// compare-exchanges between a thread's own keys need nothing, those inside a wave one lane exchange (ds_bpermute) and
+// v_min / v_max, and only the stages whose partners sit in different waves (14 of the 66 at N = 2048) go through LDS,
+// one barrier each (two buffers).  Before: every stage read and wrote 64-bit keys in LDS behind a workgroup barrier,
+// ~30 instructions per compare-exchange on 16 waves: 18.6 us of the kernel's 36 at the cfg2 size.  The hash and the
+// bounding cube share one pass over the cloud.
+template <typename T, int KPT>
 __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ points, int N, int ntiles,
                                                          int npad, PointRec<T> *__restrict__ pts,
                                                          T *__restrict__ boxes, CacheCtl cc)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *xbuf = reinterpret_cast<uint32_t *>(smem);   // [2][npad]: the cross-wave stages' exchange buffers
     __shared__ float red[6][16];
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;   // nthr * KPT == npad
     const int lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const T *cloud = points + (size_t)b * N * 3;
 
-    // ---- content hash of the raw coordinates (order-sensitive per element, order-free combination)
+    // ---- one pass: content hash of the raw coordinates (order-sensitive per element, order-free combination) and
+    //      the bounding cube (float precision is enough: the order is a performance hint only)
     unsigned long long *hred = reinterpret_cast<unsigned long long *>(smem + (size_t)npad * 8);   // [16] + flag
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     {
         unsigned long long h = 0;
-        const int nwords = N * 3 * (int)(sizeof(T) / 4);
+        constexpr int WPP = 3 * (int)(sizeof(T) / 4);   // 32-bit words per point
         const uint32_t *raw = reinterpret_cast<const uint32_t *>(cloud);
-        for (int i = tid; i < nwords; i += nthr) {
-            unsigned long long x = ((unsigned long long)(uint32_t)i << 32) | raw[i];
-            x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-            h += x;
+        for (int i = tid; i < N; i += nthr) {
+#pragma unroll
+            for (int w = 0; w < WPP; ++w) {
+                unsigned long long x = ((unsigned long long)(uint32_t)(i * WPP + w) << 32) | raw[(size_t)i * WPP + w];
+                x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+                h += x;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = (float)cloud[(size_t)i * 3 + a];
+                mn[a] = v < mn[a] ? v : mn[a];
+                mx[a] = v > mx[a] ? v : mx[a];
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
-        if (lane == 0) hred[wave] = h;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = wave_min(mn[a]);
+            mx[a] = wave_max(mx[a]);
+        }
+        if (lane == 0) {
+            hred[wave] = h;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                red[a][wave] = mn[a];
+                red[3 + a][wave] = mx[a];
+            }
+        }
         __syncthreads();
         if (tid == 0) {
             unsigned long long t = 0;
@@ -224,26 +255,6 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
         __syncthreads();
         if (hred[16] != 0) return;   // sorted records and tile boxes of this cloud are still current
     }
-
-    // bounding cube (float precision is enough: the order is a performance hint only)
-    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int i = tid; i < N; i += nthr)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = (float)cloud[(size_t)i * 3 + a];
-            mn[a] = v < mn[a] ? v : mn[a];
-            mx[a] = v > mx[a] ? v : mx[a];
-        }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        mn[a] = wave_min(mn[a]);
-        mx[a] = wave_max(mx[a]);
-        if (lane == 0) {
-            red[a][wave] = mn[a];
-            red[3 + a][wave] = mx[a];
-        }
-    }
-    __syncthreads();
     const int nwaves = nthr >> 6;
     float ext = 0.f;
 #pragma unroll
@@ -257,9 +268,13 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
         ext = (hi - lo) > ext ? (hi - lo) : ext;
     }
     const float scale = ext > 0.f ? 1023.0f / ext : 0.f;
-
-    for (int i = tid; i < npad; i += nthr) {
-        uint64_t k = ~0ull;   // padding sorts last
+    const int ib = 31 - __builtin_clz((unsigned)npad);   // bits of a point's index (npad is a power of two)
+    const int cb = ((32 - ib) / 3) * 3 > 30 ? 30 : ((32 - ib) / 3) * 3;
+    uint32_t key[KPT];
+#pragma unroll
+    for (int s = 0; s < KPT; ++s) {
+        const int i = s * nthr + tid;
+        uint32_t k = 0xFFFFFFFFu;   // padding sorts last
         if (i < N) {
             uint32_t q[3];
 #pragma unroll
@@ -268,35 +283,68 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
                 f = f < 0.f ? 0.f : (f > 1023.f ? 1023.f : f);
                 q[a] = (uint32_t)f;
             }
-            const uint32_t code = hilbert30(q[0], q[1], q[2]);
-            k = ((uint64_t)code << 32) | (uint32_t)i;
+            k = ((hilbert30(q[0], q[1], q[2]) >> (30 - cb)) << ib) | (uint32_t)i;
         }
-        keys[i] = k;
+        key[s] = k;
     }
-    __syncthreads();
 
-    for (int k = 2; k <= npad; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (npad >> 1); t += nthr) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const uint64_t a = keys[i], c = keys[l];
-                const bool up = (i & k) == 0;
-                if ((a > c) == up) {
-                    keys[i] = c;
-                    keys[l] = a;
-                }
+    // ---- bitonic network on element e = s * nthr + tid; ascending blocks where (e & k) == 0
+    int cur = 0;
+    for (int k = 2; k <= npad; k <<= 1) {
+        // partners in the same thread: distance nthr << m
+#pragma unroll
+        for (int m = KPT / 2; m >= 1; m >>= 1) {
+            if (m * nthr < k) {
+#pragma unroll
+                for (int s = 0; s < KPT; ++s)
+                    if ((s & m) == 0) {
+                        const bool up = ((s * nthr + tid) & k) == 0;
+                        const uint32_t a = key[s], c = key[s | m];
+                        const uint32_t lo = a < c ? a : c, hi = a < c ? c : a;
+                        key[s] = up ? lo : hi;
+                        key[s | m] = up ? hi : lo;
+                    }
             }
-            __syncthreads();
         }
+        // partners in other waves: through LDS, one barrier per stage (alternating buffers)
+        for (int j = (k >> 1) < (nthr >> 1) ? (k >> 1) : (nthr >> 1); j >= 64; j >>= 1) {
+            uint32_t *xb = xbuf + (size_t)cur * npad;
+#pragma unroll
+            for (int s = 0; s < KPT; ++s) xb[s * nthr + tid] = key[s];
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < KPT; ++s) {
+                const uint32_t pk = xb[s * nthr + (tid ^ j)];
+                const bool up = ((s * nthr + tid) & k) == 0, lower = (tid & j) == 0;
+                const uint32_t lo = key[s] < pk ? key[s] : pk, hi = key[s] < pk ? pk : key[s];
+                key[s] = (lower == up) ? lo : hi;
+            }
+            cur ^= 1;
+        }
+        // partners in the same wave: one lane exchange
+        for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {
+#pragma unroll
+            for (int s = 0; s < KPT; ++s) {
+                const uint32_t pk = (uint32_t)__shfl_xor((int)key[s], j);
+                const bool up = ((s * nthr + tid) & k) == 0, lower = (tid & j) == 0;
+                const uint32_t lo = key[s] < pk ? key[s] : pk, hi = key[s] < pk ? pk : key[s];
+                key[s] = (lower == up) ? lo : hi;
+            }
+        }
+    }
 
+    // ---- records and tile boxes: position p = s * nthr + tid is held by this thread, so a wave holds whole tiles
     const T inf = Limits<T>::inf();
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
-        const int p = tile * kTile + lane;
+    const uint32_t imask = (1u << ib) - 1u;
+#pragma unroll
+    for (int s = 0; s < KPT; ++s) {
+        const int p = s * nthr + tid;
+        const int tile = p >> 6;
+        if (tile >= ntiles) continue;   // (wave-uniform)
         PointRec<T> r;
         const bool v = p < N;
         if (v) {
-            const int i = (int)(uint32_t)keys[p];
+            const int i = (int)(key[s] & imask);
             r.x = cloud[(size_t)i * 3 + 0];
             r.y = cloud[(size_t)i * 3 + 1];
             r.z = cloud[(size_t)i * 3 + 2];

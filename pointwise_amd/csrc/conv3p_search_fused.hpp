@@ -301,6 +301,19 @@ __device__ __forceinline__ void fused_resolve(const Stencil<T> &st, T rvoxel, co
 
 typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// Which stencils' lists are squeezed after pass 2 (see the compaction stage of search_fused_kernel): the dilated ones.
+// A window of 16 + 2 buckets per one-voxel interval accepts ~(18/16)^3 = 1.42 x the volume: a third of a dilated
+// stencil's hits are false positives, but only a ninth of an undilated one's (its three intervals per axis merge into
+// one of 48 + 2 buckets: 12 % on the ModelNet-like clouds, 9 % on the rooms) -- there the pass costs more than the
+// walkers' shorter lists give back.
+// Undilated stencils are squeezed where the lists are long (more than 48 hits per centre on average over the tile: the
+// rooms, whose stride-1 lists serve two layers of the segmentation model; cfg4 step 1.380 -> 1.358 ms) -- the pass costs
+// per tile, the walkers save per record.  Decided per tile from its own hit count: the same for any batch it sits in.
+template <typename T> __device__ __forceinline__ bool fused_compacts(const Stencil<T> &st, uint32_t tile_hits)
+{
+    return !(CONV3P_DEV_FUSED_ABLATE & 16) && (st.step[0] * st.step[1] * st.step[2] > 1 || tile_hits > 48u * 64u);
+}
+
 // EXT3: the stencil has 3 taps per axis (all layers of the reference's models).  Tap 1's acceptance interval is then
 // centre -+ half a voxel whatever the stride and taps 0 / 2 sit 16 * step buckets below / above it: no per-tap
 // constants, the nine look-ups of a candidate tile in flight together.  Otherwise: the general loop over FusedJob::clo.
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         base = __shfl(base, 0);
         ok = __shfl(ok, 0);
         // (a tile whose reservation held gets its per-centre segments after pass 2, with the false positives squeezed out)
-        if (!ok || (CONV3P_DEV_FUSED_ABLATE & 16))
+        if (!ok || !fused_compacts(st, (uint32_t)Ltot))
             job.qsegs[((size_t)b * ntiles + qt) * ngroups * 64 + lane] = ok ? make_uint2(base + offq, nq) : make_uint2(0u, kSegOverflow);
         for (int g = 1; g < ngroups; ++g) job.qsegs[(((size_t)b * ntiles + qt) * ngroups + g) * 64 + lane] = make_uint2(0u, 0u);
         }
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
     //      record only ever moves DOWN inside its own centre's slots, so nothing unread is overwritten; the slots past
     //      the live records are rewritten as kNoTap records (tile-level readers of `segs` see no duplicates).  The live
     //      count of a centre is the sum of its populations, already in LDS.
-    if (have_pairs && ok && !(CONV3P_DEV_FUSED_ABLATE & 16)) {
+    if (have_pairs && ok && fused_compacts(st, misc[2])) {
         uint32_t *livec = nqw + 64;   // [64]; entry c is written and read by the wave that owns centre c only
         {
             const int c = wave * 16 + (lane & 15);
