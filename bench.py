@@ -30,6 +30,9 @@ Extra objects on the JSON line (rank 0; everything except `roofline` only at N=1
   op_boundary_cached_ms_per_step   the same 8 op calls through conv3p_forward/backward_cached_* with a persistent
                      neighbour cache but NO caller hints and no prefetch (every call re-validates the points on the
                      device): what a TF shim holding persistent state gets without owning the step loop.
+  op_boundary_native_ms_per_step   that op-by-op step once more WITHOUT Python: integration/op_boundary_bench (C++, the
+                     library's C ABI only) issues the 8 *_cached_* calls and the SELU ops on one stream over the same
+                     clouds, HIP-event timed; run as a subprocess outside every timed region.
   valu_issue_frac    (inside roofline) per kernel: SQ_INSTS_VALU per launch (rocprofv3 PMC pass, profiles/valu_latest.json)
                      / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction x launch duration) -- the resource the
                      cache-resident cfg2 kernels actually load, HBM being nowhere near saturated.
@@ -308,6 +311,31 @@ def cpu_baseline(points_np, feats_np, st, ups_np, budget_s=12.0):
             "cores": 1, "kind": "reference" if serial_ref else "port",
             "sample": "BASELINE config 1: B=1, N=2048, 3->9, stride 1, forward only, serial; best of %d calls" % n1}
     return base, cfg1, ref
+
+
+def op_boundary_native(Ps):
+    """The same op-by-op step WITHOUT Python: integration/op_boundary_bench (C++, links the library's C ABI only) issues
+    the 8 *_cached_* calls + SELU ops on one stream over the same clouds, HIP-event timed.  Run as a subprocess, outside
+    every timed region of this file."""
+    exe = os.path.join(ROOT, "integration", "op_boundary_bench")
+    if not os.path.exists(exe):
+        return {"op_boundary_native_ms_per_step": None, "op_boundary_native_note": "integration/op_boundary_bench not built (__graft_entry__.build())"}
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.asarray([len(Ps), Ps[0].shape[0], Ps[0].shape[1]], dtype=np.int32).tofile(f)
+        for p in Ps:
+            np.ascontiguousarray(p, dtype=np.float32).tofile(f)
+        path = f.name
+    try:
+        r = subprocess.run([exe, "50", "10", path], capture_output=True, text=True, timeout=120)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"op_boundary_native_ms_per_step": d["op_boundary_native_ms_per_step"],
+                "op_boundary_native_value": round(Ps[0].shape[0] * Ps[0].shape[1] / d["op_boundary_native_ms_per_step"] / 1e3, 3),
+                "op_boundary_native_host_enqueue_ms_per_step": d["host_enqueue_ms_per_step"]}
+    except Exception as e:   # noqa: BLE001 -- a reported figure, never a reason to lose the bench line
+        return {"op_boundary_native_ms_per_step": None, "op_boundary_native_note": "failed: %r" % (e,)}
+    finally:
+        os.unlink(path)
 
 
 def op_boundary_cached_step(st, cache, P, X, gcat):
@@ -738,6 +766,7 @@ def main():
             out["op_boundary_cached_ms_per_step"] = round(dt_b * 1e3, 4)
             out["op_boundary_cached_value"] = round(total_pts / dt_b / 1e6, 3)
             del cache
+            out.update(op_boundary_native(Ps))
             out["other_configs"] = {"cfg4": cfg4_report(lib, dev), "cfg5_shard": cfg5_report(lib, dev),
                                     "classification_head": head_report(lib, dev)}
         if world == 1 and not args.no_cpu:

@@ -170,6 +170,7 @@ template <typename T> struct Layout {
     T *boxes;
     T *cmin;   // [B][3] origin of the reference's uniform grid (stencils with an even dilated extent only)
     unsigned long long *ftab;   // [B][ntiles][kFTableU64] per-tile window tables of the fused search (sorted clouds only)
+    uint32_t *tab_version, *tab_ticket;   // [B] version of the cloud its tables were built from / tiles done (tile_tables_kernel)
     // per slot
     struct Slot {
         uint32_t *built_version, *cursor, *ticket;
@@ -218,6 +219,8 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
     L.ftab = N <= kFusedMaxPoints
                  ? reinterpret_cast<unsigned long long *>(take(sizeof(unsigned long long) * (size_t)B * ntiles * kFTableU64))
                  : nullptr;
+    L.tab_version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
+    L.tab_ticket = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
     size_t ppc = (size_t)N * (size_t)pairs_per_point;
     if ((size_t)B * ppc > 0xFFFFFFF0ull) ppc = B ? 0xFFFFFFF0ull / (size_t)B : 0;
     if (ppc > 0x7FFFFFFFull) ppc = 0x7FFFFFFFull;   // headroom for the allocator's transient overshoot (search_tile P2)
@@ -415,6 +418,8 @@ template <typename T> CacheCtl make_ctl(const Layout<T> &L, int slot, unsigned l
     cc.cursor = L.slot[slot].cursor;
     cc.ticket = L.slot[slot].ticket;
     cc.cursor_all = L.cursor_all;
+    cc.tab_version = L.tab_version;
+    cc.tab_ticket = L.tab_ticket;
     cc.nslots = (int)L.slot.size();
     cc.nclouds = L.nclouds;
     cc.tag = tag;
@@ -545,7 +550,7 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
     const float inv16 = (float)((double)kFR / (double)c.st.voxel);
     Scope sc(K_SEARCH, c.s);
     hipLaunchKernelGGL(tile_tables_kernel<T>, dim3((d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock, d.B), dim3(256), 0, c.s,
-                       c.L.pts, d.ntiles, inv16, c.L.ftab);
+                       c.L.pts, d.ntiles, inv16, c.L.ftab, c.cc.version, c.L.tab_version, c.L.tab_ticket, c.cc.force);
     bool ext3 = true;
     for (int k = 0; k < njobs; ++k)
         for (int a = 0; a < 3; ++a) ext3 &= jobs.job[k].st.ext[a] == 3;
@@ -1238,7 +1243,7 @@ int f64_blocked_backward(const Call<double> &c, const double *grad_out, const do
             TRY((launch_backward<double, kF64Ki, kF64Co>(cp, w.yp, w.xp, w.wp, w.zp, w.parts)));
             {
                 Scope sc(K_REDUCE, c.s);
-                hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3((unsigned)((nwb + 63) / 64)), dim3(1024), 0, c.s, w.parts,
+                hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3((unsigned)((nwb + kReduceW - 1) / kReduceW)), dim3(1024), 0, c.s, w.parts,
                                    nslots, nwb, w.dwp);
             }
             if (c0 == 0)
@@ -1631,7 +1636,7 @@ int backward_split_36_13(const Call<T> &c, const T *grad_out, const T *input, co
             if (rc != CONV3P_OK) return rc;
             {
                 Scope sc(K_REDUCE, c.s);
-                hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nwp + 63) / 64)), dim3(1024), 0, c.s, region,
+                hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nwp + kReduceW - 1) / kReduceW)), dim3(1024), 0, c.s, region,
                                    nslots, nwp, Wd);
             }
             hipLaunchKernelGGL(copy_cols_kernel<T>, dim3((unsigned)((nwp + 255) / 256)), dim3(256), 0, c.s, Wd, grad_filter + c0,
@@ -1732,7 +1737,7 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
     TRY(rc);
     {
         Scope sc(K_REDUCE, s);
-        hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nw + 63) / 64)), dim3(1024), 0, s,
+        hipLaunchKernelGGL(reduce_partials_kernel<T>, dim3((unsigned)((nw + kReduceW - 1) / kReduceW)), dim3(1024), 0, s,
                            c.L.partials, nslots, nw, grad_filter);
     }
     TRY(hip_ok());
@@ -2033,7 +2038,7 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
         for (int l = 0; l < stack_layers(sd); ++l)
             if (red[l].job.nslots > 0) {
                 jobs.job[nj++] = red[l].job;
-                const unsigned g = (red[l].job.nw + 63u) / 64u;
+                const unsigned g = (red[l].job.nw + (unsigned)kReduceMultiW - 1u) / (unsigned)kReduceMultiW;
                 gx = g > gx ? g : gx;
             }
         if (nj == 0) return CONV3P_OK;

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int k = kb * 16 + 4 * l4 + rr;
-                        if (k < CIN && l15 < COUT) so[((size_t)f * CIN + k) * COUT + l15] = acc0[kb][rr] + acc1[kb][rr];
+                        if (k < CIN && l15 < COUT) partial_store(&so[((size_t)f * CIN + k) * COUT + l15], acc0[kb][rr] + acc1[kb][rr]);
                     }
             }
         } else {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 
                     for (int k = 0; k < CIN; ++k) acc[k] = fma_t(g, xt[j * CIN + k], acc[k]);
                 }
 #pragma unroll
-                for (int k = 0; k < CIN; ++k) slot_out[((size_t)f * CIN + k) * COUT + c] = acc[k];
+                for (int k = 0; k < CIN; ++k) partial_store(&slot_out[((size_t)f * CIN + k) * COUT + c], acc[k]);
             }
         }
     };

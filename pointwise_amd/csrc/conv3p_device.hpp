@@ -94,6 +94,20 @@ template <typename T> __device__ __forceinline__ T wave_max(T v)
     return v;
 }
 
+// A workgroup's grad_filter partial is written once and read once, by the reduction kernel: streamed past the caches'
+// retention (nontemporal) when CONV3P_NT_PARTIALS, so that the 9 MB a backward launch leaves behind are on their way to
+// memory before the kernel's end-of-launch write-back (developer A/B: profiles/r05_nt_partials.txt)
+#ifndef CONV3P_NT_PARTIALS
+#define CONV3P_NT_PARTIALS 0   // measured: no difference on the headline (0.4174 either way), --serial 0.431 against 0.429
+#endif
+template <typename T> __device__ __forceinline__ void partial_store(T *p, T v)
+{
+#if CONV3P_NT_PARTIALS
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 

@@ -54,6 +54,7 @@ struct CacheCtl {
     uint32_t *cursor;                // [B] of the slot in use
     uint32_t *ticket;                // [B] of the slot in use
     uint32_t *cursor_all;            // [nslots][2][B]: all slots' allocators and tickets (contiguous)
+    uint32_t *tab_version, *tab_ticket;   // [B] the window tables' validity mark and completion count (tile_tables_kernel)
     int nslots, nclouds;
     unsigned long long tag;
     uint32_t epoch;
@@ -243,6 +244,9 @@ __global__ __launch_bounds__(1024) void prep_sort_kernel(const T *__restrict__ p
                 cc.version[b] += 1;
                 // every slot's lists of this cloud are stale now: their allocators restart from empty
                 for (int sl = 0; sl < 2 * cc.nslots; ++sl) cc.cursor_all[(size_t)sl * cc.nclouds + b] = 0;
+                // ... and so are its window tables (a never-initialised or re-shaped buffer may hold anything in the count)
+                cc.tab_version[b] = cc.version[b] - 1u;
+                cc.tab_ticket[b] = 0;
             }
             // the slot about to be used must allocate from an empty region if it is going to rebuild
             const bool valid = same && cc.built_version[b] == cc.version[b] && cc.built_tag[b] == cc.tag;
@@ -1526,11 +1530,11 @@ __global__ __launch_bounds__(256) void backward_kernel(
                         const int row0 = rb0 * 16 + 4 * l4 + r, row1 = rb1 * 16 + 4 * l4 + r;
                         if (n < CIN && row0 < nrows) {
                             const int f = row0 / COUT, c = row0 - f * COUT;
-                            slot[((size_t)f * CIN + n) * COUT + c] = acc0[cb][r];
+                            partial_store(&slot[((size_t)f * CIN + n) * COUT + c], acc0[cb][r]);
                         }
                         if (two && n < CIN && row1 < nrows) {
                             const int f = row1 / COUT, c = row1 - f * COUT;
-                            slot[((size_t)f * CIN + n) * COUT + c] = acc1[cb][r];
+                            partial_store(&slot[((size_t)f * CIN + n) * COUT + c], acc1[cb][r]);
                         }
                     }
             }
@@ -1601,7 +1605,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                 }
                 const int f = row / COUT, c = row - f * COUT;
 #pragma unroll
-                for (int k = 0; k < CIN; ++k) slot[((size_t)f * CIN + k) * COUT + c] = acc[k];
+                for (int k = 0; k < CIN; ++k) partial_store(&slot[((size_t)f * CIN + k) * COUT + c], acc[k]);
             }
             BDBG()
             // ---- phase C: dX rows.  lane = centre j, waves split the rows.
@@ -1660,36 +1664,65 @@ __global__ __launch_bounds__(256) void backward_kernel(
     }
 }
 
-// grad_filter[e] = sum over partial slots, fixed order (slot index ascending within a wave's
-// stripe, stripes combined in ascending wave order) -> run-to-run deterministic given
-// deterministic partials.  16 waves per workgroup stride over the slots; 64 weights per workgroup.
+// grad_filter[e] = sum over the workgroups' partial slots, in a fixed order -> run-to-run deterministic given
+// deterministic partials.  A workgroup of 16 waves serves kReduceW = 16 consecutive weights: lane = (weight, one of four
+// slot stripes), 64 stripes per workgroup, every stripe walks its slots 64 apart with four independent sums; the four
+// stripes of a wave meet by two lane exchanges, the 16 waves through LDS in ascending order.  (Round 5: until then a
+// workgroup served 64 weights -- 35 workgroups for a 9 -> 9 layer's 2 187 weights on 256 CUs, 64 dependent loads per
+// thread: 10.5 us per call at the op boundary, now ~4.)
+constexpr int kReduceW = 16;        // reduce_partials_kernel (one layer per launch: 137 workgroups for 2 187 weights)
+constexpr int kReduceMultiW = 64;   // reduce_multi_kernel (all layers of a stack, 36 MB: bound by the read, 8.7 us; measured with
+                                    // 16 weights per workgroup -- 64-byte pieces per stripe -- 13.2 us)
+// ONE summation order for both: 64 stripes per weight (stripe = slot mod 64), each summed 64 slots apart into four
+// interleaved accumulators, ((s0 + s1) + (s2 + s3)); the four stripes 4w .. 4w + 3 of "wave" w as (t0 + t2) + (t1 + t3); the
+// 16 waves in ascending order.  W = 16: a lane group of the wave per stripe, combined by two lane exchanges; W = 64: a
+// thread runs the four stripes itself.  The cached stack (multi) and the op-by-op paths (single) give the same bits.
+template <typename T, int W>
+__device__ __forceinline__ void reduce_slots(const T *__restrict__ partials, int nslots, size_t nw, T *__restrict__ grad_filter,
+                                             unsigned block, T (*part)[W])
+{
+    static_assert(W == 16 || W == 64, "stripe layouts written for 16 and 64 weights per workgroup");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wl = lane & (W - 1);
+    const size_t e = (size_t)block * W + wl;
+    auto stripe_sum = [&](int stripe) {
+        T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+        int p = stripe;
+        for (; p + 192 < nslots; p += 256) {
+            s0 += partials[(size_t)p * nw + e];
+            s1 += partials[(size_t)(p + 64) * nw + e];
+            s2 += partials[(size_t)(p + 128) * nw + e];
+            s3 += partials[(size_t)(p + 192) * nw + e];
+        }
+        for (; p < nslots; p += 64) s0 += partials[(size_t)p * nw + e];
+        return (s0 + s1) + (s2 + s3);
+    };
+    T s = (T)0;
+    if (W == 16) {
+        if (e < nw) s = stripe_sum(wave * 4 + (lane >> 4));
+        s += lane_xor32(s);   // t_g + t_(g ^ 2)   (a + b and b + a are the same value)
+        s += lane_xor16(s);   // (t0 + t2) + (t1 + t3)
+    } else if (e < nw) {
+        // (the four stripes one after the other: side by side -- 16 loads per round -- measured 13.9 us against 9.8)
+        const T t0 = stripe_sum(wave * 4), t1 = stripe_sum(wave * 4 + 1), t2 = stripe_sum(wave * 4 + 2), t3 = stripe_sum(wave * 4 + 3);
+        s = (t0 + t2) + (t1 + t3);
+    }
+    if (lane < W) part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && lane < W && e < nw) {
+        T t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t += part[w][lane];
+        grad_filter[e] = t;
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const T *__restrict__ partials,
                                                                int nslots, size_t nw,
                                                                T *__restrict__ grad_filter)
 {
-    __shared__ T part[16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t e = (size_t)blockIdx.x * 64 + lane;
-    T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
-    if (e < nw) {
-        int p = wave;
-        for (; p + 48 < nslots; p += 64) {
-            s0 += partials[(size_t)p * nw + e];
-            s1 += partials[(size_t)(p + 16) * nw + e];
-            s2 += partials[(size_t)(p + 32) * nw + e];
-            s3 += partials[(size_t)(p + 48) * nw + e];
-        }
-        for (; p < nslots; p += 16) s0 += partials[(size_t)p * nw + e];
-    }
-    part[wave][lane] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (wave == 0 && e < nw) {
-        T s = part[0][lane];
-#pragma unroll
-        for (int w = 1; w < 16; ++w) s += part[w][lane];
-        grad_filter[e] = s;
-    }
+    __shared__ T part[16][kReduceW];
+    reduce_slots<T, kReduceW>(partials, nslots, nw, grad_filter, blockIdx.x, part);
 }
 
 // The same for several layers in ONE launch (blockIdx.y = layer): the stack-level backward leaves every layer's
@@ -1707,31 +1740,10 @@ template <typename T> struct ReduceJobs {
 template <typename T>
 __global__ __launch_bounds__(1024) void reduce_multi_kernel(ReduceJobs<T> jobs)
 {
-    __shared__ T part[16][64];
+    __shared__ T part[16][kReduceMultiW];
     const ReduceJob<T> &j = jobs.job[blockIdx.y];
-    if ((size_t)blockIdx.x * 64 >= j.nw) return;   // uniform
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t e = (size_t)blockIdx.x * 64 + lane, nw = j.nw;
-    const T *partials = j.partials;
-    T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
-    if (e < nw) {
-        int p = wave;
-        for (; p + 48 < j.nslots; p += 64) {
-            s0 += partials[(size_t)p * nw + e];
-            s1 += partials[(size_t)(p + 16) * nw + e];
-            s2 += partials[(size_t)(p + 32) * nw + e];
-            s3 += partials[(size_t)(p + 48) * nw + e];
-        }
-        for (; p < j.nslots; p += 16) s0 += partials[(size_t)p * nw + e];
-    }
-    part[wave][lane] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (wave == 0 && e < nw) {
-        T s = part[0][lane];
-#pragma unroll
-        for (int w = 1; w < 16; ++w) s += part[w][lane];
-        j.grad_filter[e] = s;
-    }
+    if ((size_t)blockIdx.x * kReduceMultiW >= j.nw) return;   // uniform
+    reduce_slots<T, kReduceMultiW>(j.partials, j.nslots, (size_t)j.nw, j.grad_filter, blockIdx.x, part);
 }
 
 template <typename T>
