@@ -560,8 +560,6 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if os.environ.get("CONV3P_DEV_MAIN_PRIORITY"):      # developer experiment: the whole bench on a stream of that priority
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["CONV3P_DEV_MAIN_PRIORITY"])))
     lib = _lib.load()
     if args.workload == "cfg5":
         return main_cfg5(args, lib, dev, rank, world)
@@ -610,10 +608,8 @@ def main():
         def step():
             i = counter[0] % NBATCH
             counter[0] += 1
-            if pre and os.environ.get("CONV3P_DEV_PREFETCH_FIRST") == "1":   # developer A/B: geometry under the forward
-                stk.prefetch(tPs[(i + 1) % NBATCH])
             stk.forward(tPs[i], tXs[i])
-            if pre and os.environ.get("CONV3P_DEV_PREFETCH_FIRST") != "1":
+            if pre:
                 # the next batch's geometry (1 sort + 4 searches) goes to the side stream now and runs under this
                 # batch's backward, as a data-loader-fed training loop would do.  Every step still performs exactly
                 # one full geometry build, one forward and one backward inside the timed region.
@@ -740,6 +736,8 @@ def main():
                                                     ("short lists" if st.sparse_neighbourhoods else "long lists")
                                                     if st.sparse_neighbourhoods is not None else "on the device"},
                "roofline": roofline}
+        if os.environ.get("CONV3P_HIP_LIB"):   # developer A/B builds: never silently
+            out["config"]["hip_library_override"] = os.environ["CONV3P_HIP_LIB"]
         if world > 1:
             out["rccl_world"] = rccl_world
             out["allreduce_ms_per_step"] = None if allreduce_ms is None else round(allreduce_ms, 4)

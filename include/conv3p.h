@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CONV3P_ABI_VERSION 3
+#define CONV3P_ABI_VERSION 4
 
 /* status codes */
 #define CONV3P_OK 0

@@ -62,5 +62,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def kernel_resources(lib=LIB):
+    """[(mangled kernel name, vgprs, vgpr spills, sgpr spills, scratch bytes per lane)] from the notes of the gfx950 code
+    object inside the built library (llvm-objcopy / clang-offload-bundler / llvm-readelf of the ROCm toolchain)."""
+    import re
+    import tempfile
+    llvm = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "co.elf")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH, "--output=" + co], check=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True,
+                               text=True).stdout
+    out = []
+    for blk in notes.split("- .agpr_count:")[1:]:
+        get = lambda k: re.search(r"\.%s:\s*(\S+)" % k, blk).group(1)
+        out.append((get("name"), int(get("vgpr_count")), int(get("vgpr_spill_count")), int(get("sgpr_spill_count")),
+                    int(get("private_segment_fixed_size"))))
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -269,6 +269,7 @@ inline bool small_shape(int elem, int cin, int cout)
 inline bool deep_shape(int elem, int cin, int cout);
 struct DeepScratch;
 size_t deep_scratch_bytes(const Dims &d, size_t pair_slots);
+size_t deep_forward_bytes(const Dims &d, size_t pair_slots);
 
 // Generic backward: every pair adds Cin*Cout products to grad_filter with global atomics.  One shared copy
 // serialises them all on the same few addresses (cfg2-sized 5->7: 67 ms); the workgroups therefore spread over
@@ -292,13 +293,14 @@ inline bool wide_shape(int elem, int cin, int cout)
 {
     return elem == 4 && cin >= 1 && cout >= 1 && (cin > kWideBlk || cout > kWideBlk);
 }
-inline size_t wide_scratch_bytes(const Dims &d, size_t pair_slots)
+inline size_t wide_scratch_bytes(const Dims &d, size_t pair_slots, bool forward_only = false)
 {
     Dims db = d;
     db.Cin = kWideBlk;    // (blocks are padded to 128 or 256 channels: sized for the largest)
     db.Cout = kWideBlk;
     const size_t rows = (size_t)d.B * d.N;
-    return up(deep_scratch_bytes(db, pair_slots)) + 3 * up(rows * kWideBlk * 4) + 2 * up((size_t)d.ntap * kWideBlk * kWideBlk * 4);
+    return up(forward_only ? deep_forward_bytes(db, pair_slots) : deep_scratch_bytes(db, pair_slots)) + 3 * up(rows * kWideBlk * 4) +
+           2 * up((size_t)d.ntap * kWideBlk * kWideBlk * 4);
 }
 
 // fp64 layers outside the register-path shapes (round 4): blocks of 16 input x 4 output channels, zero-padded, on the
@@ -347,8 +349,8 @@ size_t forward_scratch_bytes(const Dims &d, int elem, int ppp = kDefaultPairsPer
 {
     if (tap_forward_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : tap_forward_bytes(d);
     if (!small_shape(elem, d.Cin, d.Cout) && deep_shape(elem, d.Cin, d.Cout))
-        return deep_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
-    if (wide_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : wide_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+        return deep_forward_bytes(d, (size_t)d.B * d.N * (size_t)ppp);
+    if (wide_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : wide_scratch_bytes(d, (size_t)d.B * d.N * (size_t)ppp, true);
     if (f64_blocked_shape(elem, d.Cin, d.Cout)) return mandatory_only ? 0 : f64_blocked_bytes(d);
     return 0;
 }
@@ -375,6 +377,8 @@ template <typename T> struct Call {
     CacheCtl cc;
     hipStream_t s;
     bool deep_scratch_ok = false;  // the scratch region can hold the deep path's side arrays
+    bool deep_fwd_ok = false;      // ... what its FORWARD needs of them (no G tiles, no partials)
+    bool wide_fwd_ok = false;      // ... the forward of the blocked path (packs placed after the forward-only deep part)
     bool tap_scratch_ok = false;   // ... the transform + gather forward's Z array
     bool wide_scratch_ok = false;  // ... the blocked path of layers with more than 256 channels
     bool f64_scratch_ok = false;   // ... the blocked path of fp64 layers outside the register-path shapes
@@ -489,11 +493,17 @@ template <typename SlotT> inline const uint32_t *sched_of(const SlotT &S)
 
 // mean pre-filter hits per point below which a slot's lists count as SHORT (populated-rows backward for the dilated narrow
 // layers): Conv3pStack.tune()'s threshold of 32 neighbours per point plus the pre-filter's ~10 % of false positives
-constexpr unsigned long long kShortListsPerPoint = 35;
-template <typename T> SchedJob make_sched_job(const Call<T> &c, int slot)
+// The regime word only matters for DILATED narrow layers (undilated ones never take the populated-rows kernel).  Of a
+// dilated stencil's hits the window tables of the fused search let through ~1.5 per neighbour (a third are false
+// positives, see fused_compacts), the tile-pair pre-filter of search_tile ~1.1: the same 32 neighbours per point are 48
+// hits there and 35 here.
+constexpr unsigned long long kShortListsPerPoint = 35, kShortListsPerPointFused = 48;
+template <typename T> bool fused_ok(const Call<T> &c);
+template <typename T> SchedJob make_sched_job(const Call<T> &c, int slot, bool fused)
 {
     const auto &S = c.L.slot[slot];
-    return SchedJob{S.segs, S.sched, S.cursor, S.regime, kShortListsPerPoint * (unsigned long long)c.d.B * (unsigned long long)c.d.N};
+    return SchedJob{S.segs, S.sched, S.cursor, S.regime,
+                    (fused ? kShortListsPerPointFused : kShortListsPerPoint) * (unsigned long long)c.d.B * (unsigned long long)c.d.N};
 }
 
 // ----------------------------------------------------------------------------- fused search (conv3p_search_fused.hpp)
@@ -529,6 +539,16 @@ template <typename T> FusedJob<T> make_fused_job(const Call<T> &c)
     return j;
 }
 // tables of every tile + ONE search launch for `njobs` stencils over the same points + the launch order of the tiles
+// hit masks of a wave's first candidate tiles kept in LDS between the passes: as many as fit 40 KiB (0: not even one fits
+// the LDS at all)
+inline int fused_mask_depth(int elem, int ntiles, int ntap_max, int maxfull_max)
+{
+    const int mmax = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    int M = std::min(mmax, (int)CONV3P_DEV_FUSED_M);
+    if (M < 1) M = 1;
+    while (M > 1 && fused_lds(ntap_max, maxfull_max, elem, M).total > 40 * 1024) --M;   // large filters: fewer stored masks
+    return fused_lds(ntap_max, maxfull_max, elem, M).total > kMaxLds ? 0 : M;
+}
 template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &jobs, const SchedJobs &sjobs, int njobs, bool schedule = true)
 {
     const Dims &d = c.d;
@@ -538,9 +558,8 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
         ntap_max = std::max(ntap_max, jobs.job[k].st.ntap);
         maxfull_max = std::max(maxfull_max, jobs.job[k].st.maxfull);
     }
-    const int mmax = (d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    int M = std::min(mmax, (int)CONV3P_DEV_FUSED_M);
-    while (M > 1 && fused_lds(ntap_max, maxfull_max, (int)sizeof(T), M).total > 40 * 1024) --M;   // large filters: fewer stored masks
+    const int M = fused_mask_depth((int)sizeof(T), d.ntiles, ntap_max, maxfull_max);
+    if (M == 0) return CONV3P_ERR_UNSUPPORTED;   // (callers test fused_fits() first and take the tile-pair search instead)
 #ifdef CONV3P_DEV_FUSED_LDS_KB   // developer: pad the LDS request (fewer workgroups per CU) to see how the kernel scales with occupancy
     const size_t lds = std::max(fused_lds(ntap_max, maxfull_max, (int)sizeof(T), M).total, (size_t)CONV3P_DEV_FUSED_LDS_KB * 1024);
 #else
@@ -568,6 +587,7 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
 
 // the other stencils a persistent cache holds, as jobs of the same launch (defined with the cache's host record below)
 template <typename T> int add_companions(const Call<T> &c, FusedJobs<T> &fj, SchedJobs &sj, int n);
+template <typename T> void note_companions_built(const Call<T> &c, const FusedJobs<T> &fj, int n);
 
 template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with_pairs)
 {
@@ -575,11 +595,11 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
     const Dims &d = c.d;
     const Stencil<T> &st = c.st;
     const auto &S = c.L.slot[c.slot];
-    if (fused_ok(c) && (!with_pairs || count == S.count)) {
+    if (fused_ok(c) && fused_mask_depth((int)sizeof(T), d.ntiles, st.ntap, st.maxfull) > 0 && (!with_pairs || count == S.count)) {
         FusedJobs<T> fj;
         SchedJobs sj;
         fj.job[0] = make_fused_job(c);
-        sj.job[0] = make_sched_job(c, c.slot);
+        sj.job[0] = make_sched_job(c, c.slot, true);
         if (!with_pairs) {   // populations only (conv3p_neighbor_count_*): into the caller's tensor, nothing else kept
             FusedJob<T> &j = fj.job[0];
             j.count = count;
@@ -590,7 +610,10 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
             j.qbm = nullptr;
             return launch_fused<T>(c, fj, sj, 1, /*schedule=*/false);
         }
-        return launch_fused<T>(c, fj, sj, add_companions<T>(c, fj, sj, 1));
+        const int nj = add_companions<T>(c, fj, sj, 1);
+        TRY(launch_fused<T>(c, fj, sj, nj));
+        note_companions_built<T>(c, fj, nj);
+        return CONV3P_OK;
     }
     const size_t lds = search_lds_bytes(st, c.L.gtiles);
     if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;   // very large filters (> ~340 taps): populations alone exceed LDS
@@ -607,7 +630,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
         else launch(search_kernel<T, false>, static_cast<const T *>(nullptr));
         if (with_pairs) {
             SchedJobs sj;
-            sj.job[0] = make_sched_job(c, c.slot);
+            sj.job[0] = make_sched_job(c, c.slot, false);
             hipLaunchKernelGGL(tile_sched_kernel, dim3(8, 1), dim3(1024), 0, c.s, sj, d.B, d.ntiles, c.L.ngroups, bm.rounds * d.ntiles);
         }
     }
@@ -861,7 +884,7 @@ struct DeepScratch {   // carved from the per-call scratch region
 // The record orders (deep_order_kernel) come FIRST and twice -- forward taps and backward taps -- at offsets that do not
 // depend on the channel counts: a geometry prefetch (CONV3P_CACHE_PREPARE_DEEP_ORDERS) builds both ahead of the
 // layer's calls, which then find them in place.  `which`: 0 = the forward's set, 1 = the backward's.
-DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base, int which, size_t *order_bytes = nullptr)
+DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base, int which, size_t *order_bytes = nullptr, size_t *forward_bytes = nullptr)
 {
     DeepScratch s{};
     size_t off = 0;
@@ -891,6 +914,7 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base, int which, 
     s.items = reinterpret_cast<uint4 *>(take((size_t)(kDwItems + 64) * 16));
     if (order_bytes) *order_bytes = off;
     s.wt = reinterpret_cast<float *>(take((size_t)d.ntap * cip * cop * 4));
+    if (forward_bytes) *forward_bytes = off;   // everything below is the backward's (work-item partials, the G tiles)
     s.partials = reinterpret_cast<float *>(take((size_t)(kDwItems + 64) * cip * cop * 4 + nw * 4));
     s.gbuf = reinterpret_cast<float *>(take((size_t)d.B * d.ntiles * d.ntap * 64 * cop * 4));
     s.bytes = off;
@@ -898,6 +922,14 @@ DeepScratch carve_deep(const Dims &d, size_t pair_slots, void *base, int which, 
 }
 
 size_t deep_scratch_bytes(const Dims &d, size_t pair_slots) { return carve_deep(d, pair_slots, nullptr, 0).bytes; }
+// what a FORWARD call of the matrix-core path touches: the record orders and the padded filter -- not the backward's G tiles
+// (B x tiles x taps x 64 x Cout floats: 3.6 GB for the cfg5 shard) nor its partials
+size_t deep_forward_bytes(const Dims &d, size_t pair_slots)
+{
+    size_t b = 0;
+    (void)carve_deep(d, pair_slots, nullptr, 0, nullptr, &b);
+    return b;
+}
 // the part of it the record orders take (the same for every channel shape)
 size_t deep_order_bytes(const Dims &d, size_t pair_slots)
 {
@@ -1004,7 +1036,7 @@ int deep_backward(const Call<float> &c, const float *grad_out, const float *inpu
     // dX = sum_f' G_f' . W[f']^T  (K = Cout, N = Cin)
     TRY((launch_deep_gemm<CO, CI, true>(c, grad_out, ds.wt, grad_input, ds, d.Cout, d.Cin, ds.gbuf, input)));
     {
-        constexpr int NH = CO >= 64 ? 2 : 1;
+        constexpr int NH = deep_dw_parts<CI, CO>();
         const size_t lds = (size_t)DEEP_DW_ROWS * (CI + 1) * 4 + (size_t)DEEP_DW_ROWS * (CO / NH + 1) * 4 + 256;
         if (lds > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
         Scope sc(K_DEEP_DW, c.s);
@@ -1035,14 +1067,17 @@ struct WideScratch {
     float *xp, *yp, *zp;   // [B N][256] packed rows: block input, block grad_out (backward), block result
     float *wp, *dwp;       // [ntap][256][256] packed filter block, its grad_filter block
 };
-inline WideScratch carve_wide(const Call<float> &c)
+inline WideScratch carve_wide(const Call<float> &c, bool forward_only = false)
 {
     const Dims &d = c.d;
     Dims db = d;
     db.Cin = kWideBlk;
     db.Cout = kWideBlk;
     const size_t rows = (size_t)d.B * d.N;
-    char *p = reinterpret_cast<char *>(c.L.partials) + up(deep_scratch_bytes(db, (size_t)d.B * c.L.pairs_per_cloud));
+    // (a forward-only workspace ends after the forward's part of the block scratch: the packs follow that; a cache sized
+    // for the backward keeps ONE placement for both passes)
+    const size_t slots = (size_t)d.B * c.L.pairs_per_cloud;
+    char *p = reinterpret_cast<char *>(c.L.partials) + up(forward_only && !c.wide_scratch_ok ? deep_forward_bytes(db, slots) : deep_scratch_bytes(db, slots));
     WideScratch w{};
     w.xp = reinterpret_cast<float *>(p); p += up(rows * kWideBlk * 4);
     w.yp = reinterpret_cast<float *>(p); p += up(rows * kWideBlk * 4);
@@ -1076,7 +1111,7 @@ int wide_forward(const Call<float> &c, const float *input, const float *filter, 
 {
     const Dims &d = c.d;
     const size_t rows = (size_t)d.B * d.N;
-    const WideScratch w = carve_wide(c);
+    const WideScratch w = carve_wide(c, /*forward_only=*/true);
     bool have_order = c.order_ok[0];
     for (int c0 = 0; c0 < d.Cout; c0 += kWideBlk) {
         const int cw = d.Cout - c0 < kWideBlk ? d.Cout - c0 : kWideBlk, cwp = wide_pad(cw);
@@ -1333,6 +1368,8 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
                             have >= deep_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
         c.tap_scratch_ok = tap_forward_shape((int)sizeof(T), d.Cin, d.Cout) && have >= tap_forward_bytes(d);
         c.wide_scratch_ok = wide_shape((int)sizeof(T), d.Cin, d.Cout) && have >= wide_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
+        c.deep_fwd_ok = deep_shape((int)sizeof(T), d.Cin, d.Cout) && have >= deep_forward_bytes(d, (size_t)d.B * c.L.pairs_per_cloud);
+        c.wide_fwd_ok = wide_shape((int)sizeof(T), d.Cin, d.Cout) && have >= wide_scratch_bytes(d, (size_t)d.B * c.L.pairs_per_cloud, true);
         c.f64_scratch_ok = f64_blocked_shape((int)sizeof(T), d.Cin, d.Cout) && have >= f64_blocked_bytes(d);
     }
     const unsigned long long tag = stencil_tag(d, stride, (double)voxel, (int)sizeof(T));
@@ -1420,12 +1457,29 @@ template <typename T> int add_companions(const Call<T> &c, FusedJobs<T> &fj, Sch
         c2.s = c.s;
         c2.cc = make_ctl(c.L, sl, h.tags[sl], c.cc.epoch, /*force=*/0);
         if (!fused_ok(c2)) continue;
+        // the launch's LDS request and the number M of hit masks a wave keeps follow the LARGEST filter among its jobs: a
+        // companion must not cost the requested stencil its masks, let alone push the launch past the LDS limit
+        if (fused_mask_depth((int)sizeof(T), c.d.ntiles, std::max(c.st.ntap, c2.st.ntap), std::max(c.st.maxfull, c2.st.maxfull)) <
+            fused_mask_depth((int)sizeof(T), c.d.ntiles, c.st.ntap, c.st.maxfull))
+            continue;
         fj.job[n] = make_fused_job(c2);
-        sj.job[n] = make_sched_job(c, sl);
-        h.built_gen[sl] = h.gen;                                      // a hinted call for it later in this generation skips its search
+        sj.job[n] = make_sched_job(c, sl, true);
         ++n;
     }
     return n;
+}
+// ... and, once the launch that carries them has been issued without error: a hinted call for one of them later in
+// this generation skips its search
+template <typename T> void note_companions_built(const Call<T> &c, const FusedJobs<T> &fj, int n)
+{
+    if (c.cache_key == nullptr || n <= 1) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_caches.find(c.cache_key);
+    if (it == g_caches.end()) return;
+    CacheHost &h = it->second;
+    for (int k = 1; k < n; ++k)
+        for (int sl = 0; sl < h.nslots; ++sl)
+            if (sl != c.slot && h.tags[sl] == fj.job[k].cc.tag) h.built_gen[sl] = h.gen;
 }
 
 // Stack-level backward: a layer's grad_filter partials stay in the caller's region and are reduced later, together
@@ -1470,7 +1524,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
     if (c.strided) return CONV3P_ERR_UNSUPPORTED;   // (a register-path shape whose LDS did not fit)
     if constexpr (sizeof(T) == 4) {
         int cip = 0, cop = 0;
-        if (c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {
+        if (c.deep_fwd_ok && deep_class(4, Cin, Cout, cip, cop)) {
 #define X(ci, co)                                                                                    \
     if (cip == ci && cop == co) {                                                                    \
         int rc = deep_forward<ci, co>(c, input, filter, output);                                     \
@@ -1481,7 +1535,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
         }
     }
     if constexpr (sizeof(T) == 4) {
-        if (c.wide_scratch_ok) {   // more than 256 channels on a side: blocks of <= 256 x 256 on the matrix-core kernels
+        if (c.wide_fwd_ok) {   // more than 256 channels on a side: blocks of <= 256 x 256 on the matrix-core kernels
             const int rc = wide_forward(c, input, filter, output);
             if (rc != CONV3P_ERR_UNSUPPORTED) return rc != CONV3P_OK || !act ? rc : selu_impl<T>(output, output, out_elems, stream);
         }
@@ -1557,7 +1611,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         const size_t l = search_lds_bytes(st, c.L.gtiles);
         if (l > kMaxLds) return CONV3P_ERR_UNSUPPORTED;
         lds = l > lds ? l : lds;
-        all_fused &= fused_ok(c);
+        all_fused &= fused_ok(c) && fused_mask_depth((int)sizeof(T), c.d.ntiles, c.st.ntap, c.st.maxfull) > 0;
         fjobs.job[njobs] = make_fused_job(c);
         SearchJob<T> &j = jobs.job[njobs++];
         j.st = st;
@@ -1568,10 +1622,12 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         j.segs = S.segs;
         j.qsegs = S.qsegs;
         j.qbm = S.qbm;
-        sjobs.job[njobs - 1] = make_sched_job(c, c.slot);
+        sjobs.job[njobs - 1] = make_sched_job(c, c.slot, true);
     }
     if (njobs == 0) return CONV3P_OK;
     if (all_fused) return launch_fused<T>(c, fjobs, sjobs, njobs);
+    for (int k = 0; k < njobs; ++k)   // (the tile-pair search lets fewer false positives through: its own threshold)
+        sjobs.job[k].limit = kShortListsPerPoint * (unsigned long long)c.d.B * (unsigned long long)c.d.N;
 #ifndef CONV3P_DEV_JOBS_IN_ORDER
     // widest stencil first (blockIdx.y ascending is the dispatch order): its boxes meet the most candidate tiles, its
     // workgroups run longest -- started last they would be the launch's tail

@@ -60,7 +60,9 @@ template <typename T> __host__ __device__ inline size_t sparse_min_rows(int cin,
 }
 
 template <typename T, int CIN, int COUT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN < 16 ? 4 : 2))) void backward_sparse_kernel(
+// (four waves per SIMD -- four workgroups per CU -- for the models' 3- and 9-input layers; 6 and 12 inputs, SceneNN's first
+// layer, which only gets here when dilated, would spill 2 / 16 registers under that cap)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 || CIN == 9) ? 4 : 2))) void backward_sparse_kernel(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const uint32_t *__restrict__ qbm, const T *__restrict__ grad_out, const T *__restrict__ input,

@@ -990,6 +990,10 @@ __global__ __launch_bounds__(256) void deep_reduce_kernel(const float *__restric
 // item; one partial per item ([CIN][COUT], each half writes its columns), summed by deep_reduce_kernel in fixed order.
 // LDS: X tile [64][CIN+1] | G tile [64][cols+1] | qorig [64]   (<= 66 KB: two workgroups per CU)
 // ---------------------------------------------------------------------------------------------
+// column parts of a work item (blockIdx.y): halves; quarters for 256 input channels, where a wave's 8 row blocks x 1
+// column block of accumulators (128 registers) plus the operands of four k-steps did not fit three waves per SIMD (35
+// spilled registers, 144 B of scratch per lane until round 5)
+template <int CIN, int COUT> constexpr int deep_dw_parts() { return CIN >= 256 && COUT >= 128 ? 4 : COUT >= 64 ? 2 : 1; }
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_DW_WAVES))) void deep_dw_kernel(
     const PointRec<float> *__restrict__ pts, const uint32_t *__restrict__ tap_off, const float *__restrict__ gbuf,
@@ -998,7 +1002,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_DW_WAV
     int cin,   // real input channels (<= CIN); the partial slots are [CIN][COUT]
     const unsigned long long *__restrict__ tap_cmask)   // [tile][tap] centres with records: the packed rows of gbuf
 {
-    constexpr int NH = COUT >= 64 ? 2 : 1;                 // column halves (blockIdx.y)
+    constexpr int NH = deep_dw_parts<CIN, COUT>();          // column parts (blockIdx.y)
     constexpr int CH = COUT / NH;
     constexpr int LDX = CIN + 1, LDG = CH + 1;
     constexpr int MB = CIN / 32, NB = CH / 32;

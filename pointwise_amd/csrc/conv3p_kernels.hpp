@@ -753,11 +753,16 @@ __global__ __launch_bounds__(1024) void tile_sched_kernel(SchedJobs jobs, int B,
     const SchedJob &jb = jobs.job[blockIdx.y];
     const int xcd = blockIdx.x;
     if (xcd == 0 && threadIdx.x < 64 && jb.regime != nullptr) {
+        // (a tile whose reservation did not fit took its request back from the allocator: such a slot's lists are long
+        // whatever the sum says)
         unsigned long long sum = 0;
+        bool over = false;
         for (int b = threadIdx.x; b < B; b += 64) sum += jb.cursor[b];
+        for (int t = threadIdx.x; t < B * ntiles * ngroups; t += 64) over |= jb.segs[t].y == kSegOverflow;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        if (threadIdx.x == 0) *jb.regime = sum <= jb.limit ? 1u : 0u;
+        const bool any_over = __any(over);
+        if (threadIdx.x == 0) *jb.regime = (!any_over && sum <= jb.limit) ? 1u : 0u;
     }
     const int nclouds = B > xcd ? (B - xcd + 7) / 8 : 0;
     const int n = nclouds * ntiles;

@@ -21,18 +21,15 @@ from . import _lib
 from . import conv3p_op as op
 from . import synth
 
-import os
-
 VOXEL = 0.1                       # tf.constant([0.1]), pointcnn2_acsd.py:46
+CLS_STRIDES = (1, 2, 3, 4)        # pointcnn2_acsd.py:47-65
+HIDDEN = 9
 
 
 def _side_stream(device):
-    """The stream the geometry of the next batch is built on.  CONV3P_DEV_SIDE_PRIORITY (developer experiments only):
-    its HIP priority (lower = more urgent; torch's default is 0)."""
-    pr = os.environ.get("CONV3P_DEV_SIDE_PRIORITY")
-    return torch.cuda.Stream(device=device, priority=int(pr)) if pr else torch.cuda.Stream(device=device)
-CLS_STRIDES = (1, 2, 3, 4)        # pointcnn2_acsd.py:47-65
-HIDDEN = 9
+    """The stream the geometry of the next batch is built on.  (HIP stream priorities for it or for the step's own
+    stream were measured twice, rounds 2 and 4: no effect -- profiles/HISTORY.md.)"""
+    return torch.cuda.Stream(device=device)
 
 
 class Conv3pStack:

@@ -11,7 +11,7 @@ import torch
 
 from oracle import oracle
 from pointwise_amd import _lib, conv3p_op as op, stack, synth
-from tests.parity_util import TOL, make_case, rel_err
+from tests.parity_util import TOL, exact_from_oracle_lists, make_case, rel_err
 
 pytestmark = pytest.mark.gpu
 VOX = 0.1
@@ -250,12 +250,10 @@ def test_full_size_matches_oracle_cfg2_layer(dev, cfg2):
 
 
 # ------------------------------------------------------------------ BASELINE configs 4 and 5 at full size
-def test_full_size_cfg5_shard(dev):
-    """BASELINE config 5, one GPU's shard at FULL size: B=16 clouds of N=8192 SceneNN-shaped points, one conv3p
-    layer 128->256, stride 1 (matrix-core path).  neighbour counts exact vs the oracle on 2 clouds; y / dX / dW of
-    cloud 3 against the oracle on channel slices (every output channel of the reference loops is an independent
-    sum -- y over c, dX over k, dW over (k, c) -- so a slice of the filter gives exactly those channels);
-    linearity and batch independence on the whole shard."""
+@pytest.fixture(scope="module")
+def cfg5(dev):
+    """BASELINE config 5, one GPU's shard at FULL size: B=16 clouds of N=8192 SceneNN-shaped points, one conv3p layer
+    128->256, stride 1 (matrix-core path): inputs (numpy + device) and the op's results on the whole shard."""
     B, N, ci, co = 16, 8192, 128, 256
     s = (1, 1, 1)
     P = synth.room_like(B, N, 7, extent=(2.4, 2.4, 3.0))
@@ -265,20 +263,84 @@ def test_full_size_cfg5_shard(dev):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     tp, tx, tw, tdy = t(P), t(X), t(W), t(dY)
     cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=27, max_cin=ci, max_cout=co)
-    cnt = op.neighbor_count(tp, (3, 3, 3), s, VOX)
-    assert np.array_equal(cnt[:2].cpu().numpy(), oracle.neighbor_count(P[:2], (3, 3, 3), s, VOX))
     y = op.conv3p(tp, tx, tw, s, VOX, cache=cache)
     dx, dw = op.conv3p_grad(tdy, tp, tx, tw, s, VOX, cache=cache)
-    b = 3
-    cs, ks = slice(40, 56), slice(100, 108)                          # 16 output channels, 8 input channels
-    y_ref = oracle.forward(P[b:b + 1], X[b:b + 1], W[..., cs], s, VOX)
-    assert rel_err(y[b:b + 1, :, cs].cpu().numpy(), y_ref) <= 1e-5
-    dx_ref, _ = oracle.backward(dY[b:b + 1], P[b:b + 1], X[b:b + 1, :, ks], W[:, :, :, ks, :], s, VOX)
-    assert rel_err(dx[b:b + 1, :, ks].cpu().numpy(), dx_ref) <= 1e-5
-    # grad_filter of cloud b alone (the op called on that cloud), slice (k, c)
+    return dict(P=P, X=X, W=W, dY=dY, tp=tp, tx=tx, tw=tw, tdy=tdy, cache=cache, y=y, dx=dx, dw=dw, s=s)
+
+
+def test_full_size_cfg5_every_channel_of_two_clouds(dev, cfg5):
+    """Every one of the 256 output channels of y, the 128 input channels of dX and the 27 x 128 x 256 entries of dW, of
+    two whole clouds of the cfg5 shard, against the oracle.  The reference's loops make every output channel an
+    independent sum -- y over c, dX over k, dW over (k, c) -- so a slice of the filter (and of X for dW) gives exactly
+    those channels: 16 forward calls on 16-channel slices of the output and 16 backward calls on 8-channel slices of the
+    input per cloud cover everything; the calls (single-threaded C, the GIL released) run side by side on the host's
+    cores.  dW is compared per cloud (the op called on that cloud alone): the sharp form of the one cross-cloud reduction.
+
+    What it is compared WITH: at this depth (sums of ~10 000 terms per output) the reference's own fp32 loops are
+    8e-6 / 5e-6 / 8e-6 (y / dX / dW, relative to the tensor's maximum) away from the exact sums -- measured,
+    profiles/r05_deep_accuracy.txt -- which leaves no room under a 1e-5 bound against THEM (the matrix-core path itself
+    is 2e-6 / 2e-6 / 2e-7 away).  The op's tolerance is therefore asserted against the exact sums over the oracle's own
+    pair lists (parity_util.exact_from_oracle_lists: the reference's single-precision decisions, float64 accumulation),
+    together with: no further from them than the reference's own single-precision loops are."""
+    from concurrent.futures import ThreadPoolExecutor
+    P, X, W, dY, s = cfg5["P"], cfg5["X"], cfg5["W"], cfg5["dY"], cfg5["s"]
+    clouds = (3, 11)
+    y_gpu = cfg5["y"].cpu().numpy()
+    dx_gpu = cfg5["dx"].cpu().numpy()
+    dw_gpu = {}
+    for b in clouds:   # grad_filter of cloud b alone
+        _, dwb = op.conv3p_grad(cfg5["tdy"][b:b + 1].contiguous(), cfg5["tp"][b:b + 1].contiguous(), cfg5["tx"][b:b + 1].contiguous(),
+                                cfg5["tw"], s, VOX)
+        dw_gpu[b] = dwb.cpu().numpy()
+
+    def fwd_task(b, c0):
+        cs = slice(c0, c0 + 16)
+        return ("y", b, cs, oracle.forward(P[b:b + 1], X[b:b + 1], np.ascontiguousarray(W[..., cs]), s, VOX))
+
+    def bwd_task(b, k0):
+        ks = slice(k0, k0 + 8)
+        dx_ref, dw_ref = oracle.backward(dY[b:b + 1], P[b:b + 1], np.ascontiguousarray(X[b:b + 1, :, ks]),
+                                         np.ascontiguousarray(W[:, :, :, ks, :]), s, VOX)
+        return ("d", b, ks, dx_ref, dw_ref)
+
+    tasks = [(bwd_task, b, k0) for b in clouds for k0 in range(0, 128, 8)] + [(fwd_task, b, c0) for b in clouds for c0 in range(0, 256, 16)]
+    single = dict(y=np.zeros((len(clouds),) + y_gpu.shape[1:], np.float32), dx=np.zeros((len(clouds),) + dx_gpu.shape[1:], np.float32),
+                  dw={b: np.zeros(W.shape, np.float32) for b in clouds})
+    with ThreadPoolExecutor(max_workers=max(1, min(64, os.cpu_count() or 1))) as ex:
+        fut = ex.map(lambda a: a[0](a[1], a[2]), tasks)
+        exact = {b: exact_from_oracle_lists(P[b], X[b], W, dY[b], s, VOX) for b in clouds}   # (BLAS, beside the C loops)
+        for r in fut:
+            i = clouds.index(r[1])
+            if r[0] == "y":
+                single["y"][i, :, r[2]] = r[3][0]
+            else:
+                single["dx"][i, :, r[2]] = r[3][0]
+                single["dw"][r[1]][:, :, :, r[2], :] = r[4]
+    for i, b in enumerate(clouds):
+        ye, dxe, dwe = exact[b]
+        for name, got, ref32, ref64, tol in (("y", y_gpu[b], single["y"][i], ye, 1e-5), ("dx", dx_gpu[b], single["dx"][i], dxe, 1e-5),
+                                             ("dw", dw_gpu[b], single["dw"][b], dwe, 2e-5)):
+            e_hip, e_ref = rel_err(got, ref64), rel_err(ref32, ref64)
+            assert e_hip <= tol and e_hip <= e_ref, (name, b, e_hip, e_ref)
+
+
+def test_full_size_cfg5_shard(dev, cfg5):
+    """The whole cfg5 shard: neighbour counts exact vs the oracle on 2 clouds; batch independence, linearity and the
+    adjoint identities over all 16 clouds (test_full_size_cfg5_every_channel_of_two_clouds holds the oracle comparison
+    of every channel); one more cloud on channel slices."""
+    P, X, W, dY, s = cfg5["P"], cfg5["X"], cfg5["W"], cfg5["dY"], cfg5["s"]
+    tp, tx, tw, tdy, cache = cfg5["tp"], cfg5["tx"], cfg5["tw"], cfg5["tdy"], cfg5["cache"]
+    y, dx, dw = cfg5["y"], cfg5["dx"], cfg5["dw"]
+    cnt = op.neighbor_count(tp, (3, 3, 3), s, VOX)
+    assert np.array_equal(cnt[:2].cpu().numpy(), oracle.neighbor_count(P[:2], (3, 3, 3), s, VOX))
+    b = 7
+    # a third cloud, every channel, against the exact sums over the oracle's pair lists (see the test above)
+    ye, dxe, dwe = exact_from_oracle_lists(P[b], X[b], W, dY[b], s, VOX)
+    assert rel_err(y[b].cpu().numpy(), ye) <= 1e-5
+    assert rel_err(dx[b].cpu().numpy(), dxe) <= 1e-5
+    # grad_filter of cloud b alone (the op called on that cloud)
     _, dw_b = op.conv3p_grad(tdy[b:b + 1].contiguous(), tp[b:b + 1].contiguous(), tx[b:b + 1].contiguous(), tw, s, VOX)
-    _, dw_ref = oracle.backward(dY[b:b + 1, :, cs], P[b:b + 1], X[b:b + 1, :, ks], W[:, :, :, ks, cs], s, VOX)
-    assert rel_err(dw_b[:, :, :, ks, cs].cpu().numpy(), dw_ref) <= 2e-5
+    assert rel_err(dw_b.cpu().numpy(), dwe) <= 2e-5
     # batch independence: cloud b inside the shard == cloud b alone; grad_filter of the shard == sum over clouds
     y_b = op.conv3p(tp[b:b + 1].contiguous(), tx[b:b + 1].contiguous(), tw, s, VOX)
     assert float((y_b[0] - y[b]).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))

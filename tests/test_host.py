@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_load_binds_and_reports_version():
     lib = _lib.load()
-    assert lib.conv3p_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.conv3p_abi_version() == _lib.ABI_VERSION == 4
     assert _lib.status_string(0) == "ok"
     assert "workspace" in _lib.status_string(_lib.ERR_WORKSPACE)
     assert lib.conv3p_profile_kinds() >= 5
@@ -163,3 +163,19 @@ def test_tf_shim_is_well_formed_against_the_declared_api():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run(["make", "-C", os.path.join(root, "integration"), "check"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_no_kernel_of_the_library_spills_vector_registers():
+    """A spilled vector register costs a scratch access inside loops that live on their gather queues (one spill drained
+    the populated-rows backward's pipeline): the code object's notes must show none -- for the
+    models' shapes (3 / 6 / 9 / 12 -> 9, 36 -> 13), the matrix-core classes (deep_gemm / deep_dw / deep_order), the
+    search and every other kernel of the library."""
+    from pointwise_amd import build
+    res = build.kernel_resources()
+    names = [r[0] for r in res]
+    for must in ("forward_kernelIfLi9ELi9E", "forward_kernelIfLi12ELi9E", "backward_sparse_kernelIfLi9ELi9E",
+                 "backward_sparse_kernelIfLi36ELi13E", "backward_kernelIfLi3ELi9E", "deep_dw_kernelILi256ELi256E",
+                 "deep_gemm_kernelILi256ELi128ELb1E", "search_fused_kernelIfLb1E"):
+        assert any(must in n for n in names), must + ": kernel not found in the code object"
+    spilled = [(n, vs) for n, _, vs, _, _ in res if vs != 0]
+    assert not spilled, spilled
