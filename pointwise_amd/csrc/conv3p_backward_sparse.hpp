@@ -483,7 +483,105 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
             }
         }
     };
+    // ---- phase C of the wide layers (fp32, >= 16 inputs) on the matrix cores.  The vector-ALU form above fetches its
+    // 36 x 13 weights per tap through the scalar path in batches of 16 and waits for each: 36 us of a 36 -> 13 tile's
+    // 130 on the rooms, 121 of the heaviest tile's 460 (profiles/r05_phase_trace_36_13.txt) -- the tile the whole launch
+    // waits for.  Here: dX[centre][k] += sum_c G[slot(centre, f')][c] . W[f'][k][c] as v_mfma_f32_16x16x4_f32 with
+    // M = centres (four blocks of 16), N = input channels (blocks of 16), K = output channels four at a time;
+    // A[i][kk] = G[slot][4 cs + kk] (0 where the centre has no row for the tap), B[kk][n] = W[f'][16 kb + n][4 cs + kk]
+    // from a [Cin][4] slice of the tap's filter block staged in the wave's scratch (one 16-byte load per input channel).
+    // A wave takes the taps f' == wave (mod 4) for all 64 centres, as above; accumulators stay in registers across the
+    // taps and the rounds.  An exact fmaf chain per output: deterministic.
+#ifndef CONV3P_SP_MFMA_C_NARROW
+#define CONV3P_SP_MFMA_C_NARROW 0   // developer A/B: 1 = the 9-input layers take it too (measured: 46.3 against 46.1 us, no gain)
+#endif
+    constexpr bool kMfmaC = sizeof(T) == 4 && (CIN >= 16 || (CONV3P_SP_MFMA_C_NARROW && CIN == 9));
+    constexpr int NKC = (CIN + 15) / 16;
+    // (the narrow layers, at 128 registers, keep the accumulators only where a tile takes ONE round -- every tile of the
+    // models' dilated strides: across rounds they would sit in registers through phase A)
+    constexpr bool kMfmaCRounds = sizeof(T) == 4 && CIN >= 16;
+    auto zero_acc = [&](f32x4 (&acc)[4][NKC]) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int kb = 0; kb < NKC; ++kb) acc[mb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // D fragment -> the waves' partial rows: register r of lane l is D[centre = 16 mb + 4 (l >> 4) + r][k = 16 kb + (l & 15)]
+    auto red_from_acc = [&](const f32x4 (&acc)[4][NKC]) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int kb = 0; kb < NKC; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * kb + (lane & 15);
+                    if (k < CIN) red[((size_t)wave * CIN + k) * 64 + 16 * mb + 4 * (lane >> 4) + r] = acc[mb][kb][r];
+                }
+    };
+    auto phase_C_mfma = [&](int t0, int t1, f32x4 (&accC)[4][NKC]) {
+        if constexpr (kMfmaC) {
+            const int l15 = lane & 15, l4 = lane >> 4;
+            // tap sets and lower-centre masks of the four centres this lane feeds into the A operand (computed here, not
+            // kept across phase A: the narrow layers run at 128 registers)
+            uint32_t bmc[4];
+            uint64_t ltc[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int ci = 16 * mb + l15;
+                bmc[mb] = (uint32_t)__shfl((int)mybm, ci);
+                ltc[mb] = ci == 0 ? 0ull : (~0ull >> (64 - ci));
+            }
+            float *wb = soa;                                   // [CIN][4] slice of W[f'] (the wave's scratch: 192 floats)
+            static_assert(!kMfmaC || CIN * 4 <= 192, "phase C: the staged filter slice must fit the wave's scratch");
+            const float *Gf = reinterpret_cast<const float *>(G);
+            const float *ff = reinterpret_cast<const float *>(filter);
+            constexpr int NCS = (COUT + 3) / 4;
+            for (int f = t0 + ((wave - t0) & (kWavesPerBlock - 1)); f < ((CONV3P_SP_ABLATE & 4) ? t0 : t1); f += kWavesPerBlock) {
+                const TapInfo ti = tapinfo[f];
+                const uint64_t m = ((uint64_t)ti.mask_hi << 32) | ti.mask_lo;
+                if (m == 0ull) continue;                       // (uniform)
+                uint32_t slot[4];
+                bool has[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    has[mb] = (bmc[mb] >> f) & 1u;
+                    slot[mb] = has[mb] ? ti.base + (uint32_t)__popcll(m & ltc[mb]) : 0u;
+                }
+#pragma unroll
+                for (int cs = 0; cs < NCS; ++cs) {
+                    // W[f'][k = lane][4 cs .. 4 cs + 3]: the last slice is read from the row's end backwards and shifted
+                    const int c0 = 4 * cs;
+                    const int start = c0 + 4 <= COUT ? c0 : COUT - 4, sh = c0 - start;
+                    const int krow = lane < CIN ? lane : 0;
+                    const float4_a4 wv = *reinterpret_cast<const float4_a4 *>(ff + ((size_t)f * CIN + krow) * COUT + start);
+                    const float w4[4] = {wv.x, wv.y, wv.z, wv.w};
+                    __builtin_amdgcn_wave_barrier();           // the previous slice's readers are done (program order)
+                    if (lane < CIN) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) wb[lane * 4 + u] = (c0 + u < COUT) ? w4[(u + sh) & 3] : 0.0f;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int c = c0 + l4;
+                    float bv[NKC];
+#pragma unroll
+                    for (int kb = 0; kb < NKC; ++kb) {
+                        const int k = 16 * kb + l15;
+                        bv[kb] = wb[(k < CIN ? k : 0) * 4 + l4];
+                        bv[kb] = k < CIN ? bv[kb] : 0.0f;
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        float a = Gf[(size_t)slot[mb] * COUT + (c < COUT ? c : 0)];
+                        a = (has[mb] && c < COUT) ? a : 0.0f;
+#pragma unroll
+                        for (int kb = 0; kb < NKC; ++kb) accC[mb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[kb], accC[mb][kb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
     T dx[CIN];
+    bool red_written = false;   // (uniform)
     SDBG()
     if (nrounds == 1) {
         // the common case (every tile of the models' strides >= 2): nothing but phase A's own state is live across it
@@ -498,26 +596,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
         SDBG()
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
-        phase_C(0, st.ntap, dx);
-        SDBG()
+        if constexpr (kMfmaC) {
+            f32x4 acc1[4][NKC];
+            zero_acc(acc1);
+            phase_C_mfma(0, st.ntap, acc1);
+            SDBG()
+            __syncthreads();   // red aliases G: every wave is done with phase C
+            red_from_acc(acc1);
+            red_written = true;
+        } else {
+            phase_C(0, st.ntap, dx);
+            SDBG()
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
+        f32x4 accR[kMfmaCRounds ? 4 : 1][kMfmaCRounds ? NKC : 1];
+        if constexpr (kMfmaCRounds) zero_acc(accR);
+#if CONV3P_SP_ABLATE & 128
+        long long ra_ = 0, rb_ = 0, rc_ = 0, rs_ = 0, t_;
+#define RDBG(v) { __builtin_amdgcn_s_waitcnt(0); const long long n_ = wall_clock64(); v += n_ - t_; t_ = n_; }
+        __builtin_amdgcn_s_waitcnt(0); t_ = wall_clock64();
+#else
+#define RDBG(v)
+#endif
         for (int r = 0; r < nrounds; ++r) {
             const int t0 = (int)rinfo[1 + r], t1 = (int)rinfo[2 + r];
             if (r > 0) __syncthreads();   // the previous round's phases B / C are done with G
             zero_G(t1);
             __syncthreads();
+            RDBG(rs_)
             phase_A(t0, t1);
+            RDBG(ra_)
             __syncthreads();
+            RDBG(rs_)
             phase_B(t0, t1);
-            phase_C(t0, t1, dx);
+            RDBG(rb_)
+            if constexpr (kMfmaCRounds) phase_C_mfma(t0, t1, accR);
+            else phase_C(t0, t1, dx);
+            RDBG(rc_)
         }
+        if constexpr (kMfmaCRounds) {
+            __syncthreads();   // red aliases G: every wave is done with its last phase C
+            red_from_acc(accR);
+            red_written = true;
+        }
+#if CONV3P_SP_ABLATE & 128
+        if (lane == 0 && (blockIdx.x % 211) == 7)
+            printf("bsp<%d,%d> wg %d wave %d: rounds %d  prologue %lld  syncs %lld  phaseA %lld  B %lld  C %lld\n", CIN, COUT, (int)blockIdx.x, wave,
+                   nrounds, st_[1] - st_[0], rs_, ra_, rb_, rc_);
+#endif
     }
     // ---- grad_input rows: fixed-order sum of the four waves' partial rows
-    __syncthreads();   // red aliases G: every wave is done with its last phase C
+    if (!red_written) {
+        __syncthreads();   // red aliases G: every wave is done with its last phase C
 #pragma unroll
-    for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
+        for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
         const int k = e >> 6;   // e & 63 == lane
