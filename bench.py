@@ -472,6 +472,10 @@ def cfg5_report(lib, dev, steps=5, warmup=2):
     dt, kinds = run(True)
     useful = 3 * 2 * 27 * ci * co * B * N            # fwd + dX + dW, dense-equivalent
     achieved = useful / dt / 1e12
+    # the matrix instructions actually ISSUED per step (SQ_INSTS_MFMA of a separate rocprofv3 --pmc pass over the same
+    # workload, profiles/deep_mfma_latest.json): only populated (tile, tap) products are issued
+    mf, mf_stale = load_counters("deep_mfma")
+    issued = None if mf is None else mf["mfma_instructions_per_step"] * mf["flops_per_instruction"] / dt / 1e12
     return {"workload": "cfg5 per-GPU shard: B=16 x N=8192 SceneNN-shaped rooms, one conv3p layer 128->256, stride 1, "
                         "forward+backward, a different batch every step, the next batch's geometry (sort + search) built in a "
                         "second cache on a side stream during the step (as the headline does); ms_per_step_geometry_in_line: "
@@ -480,14 +484,17 @@ def cfg5_report(lib, dev, steps=5, warmup=2):
             "value": round(B * N / dt / 1e6, 3), "unit": "Mpoints/s",
             "roofline": {"bound": "mfma", "scope": "whole step", "achieved": round(achieved, 2),
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                         "achieved_issued": None if issued is None else round(issued, 2),
+                         "frac_issued": None if issued is None else round(issued / MFMA_F32_PEAK_TFLOPS, 4),
+                         "counters_stale": bool(mf_stale),
                          "flops_per_point": 3 * 2 * 27 * ci * co,
                          "note": "useful (dense-equivalent) flops = 3 x 2*27*Cin*Cout per point; the matrix "
-                                 "instructions ISSUED are fewer (only populated (tile, tap) products run) -- see "
-                                 "profiles/ for SQ_INSTS_MFMA"},
+                                 "instructions ISSUED are fewer (only populated (tile, tap) products run): "
+                                 "achieved_issued / frac_issued = SQ_INSTS_MFMA x 4096 flops over the same step time"},
             "kernel_ms_per_step": {k: round(v[1] / 2, 4) for k, v in kinds.items()},
             "kernel_ms_per_step_note": "HIP events around each launch in the prefetch leg: prep / search / deep_order run on "
                                        "the side stream beside the main stream's kernels, so their figures are overlapped "
-                                       "LATENCIES, not kernel cost (alone: profiles/r04_deep_kernel_stats.txt, r04_geometry_time.txt)"}
+                                       "LATENCIES, not kernel cost (alone: profiles/r05_deep_kernel_stats.txt, r05_geometry_time.txt)"}
 
 
 def head_report(lib, dev, steps=20, warmup=3):

@@ -34,6 +34,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_deep_trace -o t -- python $ROOT/
 python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_trace/t_results.db deep > $OUT/${TAG}_deep_kernel_stats.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_deep_pmc -o p -- python $ROOT/tools/deep_time.py > $OUT/${TAG}_deep_pmc.log 2>&1
 python $ROOT/tools/pmc_query.py $OUT/${TAG}_deep_pmc/p_results.db deep > $OUT/${TAG}_deep_pmc_MFMA.txt 2>&1
+python $ROOT/tools/mfma_json.py $OUT/${TAG}_deep_pmc_MFMA.txt > $OUT/${TAG}_deep_mfma.json
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d $OUT/${TAG}_deep_pmc_$C -o p -- python $ROOT/tools/deep_time.py > $OUT/${TAG}_deep_pmc_$C.log 2>&1
 done
