@@ -545,6 +545,10 @@ inline int fused_mask_depth(int elem, int ntiles, int ntap_max, int maxfull_max)
 {
     const int mmax = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     int M = std::min(mmax, (int)CONV3P_DEV_FUSED_M);
+    // small clouds (<= 32 tiles: a wave meets two or three candidate tiles): ONE stored mask -- 31 KiB instead of 41, a
+    // fifth workgroup per CU; recomputing the others in pass 2 costs less than the occupancy gives (cfg2 search alone
+    // 111 -> 106 us, under the backward 141 -> 123; on the rooms' 64 tiles per cloud the step does not move)
+    if (ntiles <= 32) M = 1;
     if (M < 1) M = 1;
     while (M > 1 && fused_lds(ntap_max, maxfull_max, elem, M).total > 40 * 1024) --M;   // large filters: fewer stored masks
     return fused_lds(ntap_max, maxfull_max, elem, M).total > kMaxLds ? 0 : M;
