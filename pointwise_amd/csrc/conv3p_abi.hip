@@ -760,7 +760,9 @@ template <typename T> int sparse_cap(const Stencil<T> &st, int cin, int cout, si
     // Undilated stencils populate a third of a centre's taps and more (adjacent cells: 9 of 27 on the ModelNet-shaped
     // clouds, 650-850 rows per tile): their tiles would take two rounds, each walking the pair lists again
     // (measured: 3 -> 9 stride 1 at the cfg2 size 63.8 us against 49.5 us dense).  Dilated ones: 210-450 rows.
+#ifndef CONV3P_DEV_SPARSE_UNDILATED   // developer A/B build: the populated-rows kernel for undilated narrow layers too
     if (cin < 16 && st.step[0] * st.step[1] * st.step[2] == 1) return 0;
+#endif
     const size_t fixed = sparse_fixed_lds<T>(st.maxfull, st.ntap, cin, cout) + 64;
     const size_t budgets[3] = {40960, 54608, 81920};
     for (size_t bud : budgets) {

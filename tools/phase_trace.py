@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import torch
     from pointwise_amd import conv3p_op as op, synth
-    S = int(sys.argv[2])
+    S = int(sys.argv[2]); CI = int(sys.argv[3]) if len(sys.argv) > 3 else 9
     dev = torch.device("cuda:0")
-    B, N, ci, co = 32, 2048, 9, 9
+    B, N, ci, co = 32, 2048, CI, 9
     P = synth.modelnet_like(B, N, 40)
     t = lambda a: torch.from_numpy(a).to(dev)
     tp, tx, tw, tdy = t(P), t(synth.features(B, N, ci, 1, points=P)), t(synth.filter_weights(3, 3, 3, ci, co, 2)), t(synth.upstream_grad(B, N, co, 3))
@@ -21,7 +21,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         torch.cuda.synchronize()
     sys.exit(0)
 S = sys.argv[1] if len(sys.argv) > 1 else "2"
-out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", S], capture_output=True, text=True).stdout
+CIARG = sys.argv[2] if len(sys.argv) > 2 else "9"
+out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", S, CIARG], capture_output=True, text=True).stdout
 out = out.split("==== last")[-1]
 for pat in ("fwd<", "bsp<", "bwd<"):
     rows = [l for l in out.splitlines() if l.startswith(pat)]
