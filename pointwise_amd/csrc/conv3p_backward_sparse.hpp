@@ -34,6 +34,9 @@
 #ifndef CONV3P_SP_CHSPLIT
 #define CONV3P_SP_CHSPLIT 1   // developer A/B: 0 = a centre's sub-lanes take different records (merged by lane swaps)
 #endif
+#ifndef CONV3P_SP_FUSE_BC
+#define CONV3P_SP_FUSE_BC 1   // developer A/B: 0 = phase B over all taps, then phase C (9 -> 9 at the cfg2 size: 45.8 us against 45.1)
+#endif
 #ifndef CONV3P_SP_ABLATE
 #define CONV3P_SP_ABLATE 0   // developer ablation switch (tools/ablate_sparse.sh); 0 in every shipped build
 #endif
@@ -592,10 +595,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
         SDBG()
         __syncthreads();
         SDBG()
-        phase_B(0, st.ntap);
-        SDBG()
 #pragma unroll
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
+#if CONV3P_SP_FUSE_BC
+        if constexpr (!kMfmaC) {
+            // phases B and C tap by tap (both give wave w the taps f' == w (mod 4)): C's weights arrive through the scalar
+            // path while B's products of the same tap are in the matrix pipe
+            for (int f = wave; f < st.ntap; f += kWavesPerBlock) {
+                phase_B(f, f + 1);
+                phase_C(f, f + 1, dx);
+            }
+            SDBG()
+        } else
+#endif
+        phase_B(0, st.ntap);
+        SDBG()
         if constexpr (kMfmaC) {
             f32x4 acc1[4][NKC];
             zero_acc(acc1);
@@ -605,7 +619,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
             red_from_acc(acc1);
             red_written = true;
         } else {
+#if !CONV3P_SP_FUSE_BC
             phase_C(0, st.ntap, dx);
+#endif
             SDBG()
         }
     } else {
