@@ -35,7 +35,7 @@
 #define CONV3P_SP_CHSPLIT 1   // developer A/B: 0 = a centre's sub-lanes take different records (merged by lane swaps)
 #endif
 #ifndef CONV3P_SP_FUSE_BC
-#define CONV3P_SP_FUSE_BC 1   // developer A/B: 0 = phase B over all taps, then phase C (9 -> 9 at the cfg2 size: 45.8 us against 45.1)
+#define CONV3P_SP_FUSE_BC 0   // developer A/B: 1 = phases B and C of a one-round tile interleaved tap by tap (9 -> 9 at the cfg2 size: 45.1 us against 45.8, but 2 spilled registers at the 128-register cap: not shipped)
 #endif
 #ifndef CONV3P_SP_ABLATE
 #define CONV3P_SP_ABLATE 0   // developer ablation switch (tools/ablate_sparse.sh); 0 in every shipped build
