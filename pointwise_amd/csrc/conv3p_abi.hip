@@ -1754,8 +1754,12 @@ int backward_impl(const T *grad_out, const T *points, const T *input, const T *f
         return CONV3P_OK;
     }
     if (rc == CONV3P_ERR_UNSUPPORTED && !defer && sizeof(T) == 8 && Cin == 36 && Cout == 13 &&
-        small_shape((int)sizeof(T), Cin, Cout))
-        return backward_split_36_13<T>(c, grad_out, input, filter, grad_input, grad_filter);
+        small_shape((int)sizeof(T), Cin, Cout)) {
+        // (filters of more than 27 taps do not fit LDS even in column blocks: its first launch says so before anything is
+        // written, and the generic kernels below take the call -- found by tools/fuzz_gpu.py, 3 x 5 x 3 taps in fp64)
+        const int src = backward_split_36_13<T>(c, grad_out, input, filter, grad_input, grad_filter);
+        if (src != CONV3P_ERR_UNSUPPORTED) return src;
+    }
     if constexpr (sizeof(T) == 4) {
         int cip = 0, cop = 0;
         if (rc == CONV3P_ERR_UNSUPPORTED && c.deep_scratch_ok && deep_class(4, Cin, Cout, cip, cop)) {

@@ -68,6 +68,7 @@ CASES = [
     ("modelnet", 4, 2048, 9, 9, (3, 3, 3), (4, 4, 4), np.float32),
     ("room", 2, 4096, 9, 9, (3, 3, 3), (1, 1, 1), np.float32),
     ("room", 2, 4096, 36, 13, (3, 3, 3), (1, 1, 1), np.float32),
+    ("room", 1, 127, 36, 13, (3, 5, 3), (4, 1, 4), np.float64),   # 45 taps in fp64: not even the column blocks fit LDS (generic kernels)
     ("room", 1, 1024, 12, 9, (3, 3, 3), (2, 2, 2), np.float32),
     ("lattice", 2, 1024, 9, 9, (3, 3, 3), (2, 2, 2), np.float32),
     ("lattice", 2, 1024, 3, 9, (3, 3, 3), (1, 1, 1), np.float32),
