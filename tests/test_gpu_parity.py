@@ -1307,3 +1307,54 @@ def test_stack_tune_sets_the_hint_by_measured_density(dev):
     assert rel_err(dx.cpu().numpy(), ref_dx) <= 2e-5 and rel_err(fused.cpu().numpy(), ref_fused) <= 2e-5
     rooms = stack.Conv3pStack(9, 13, device=dev, seed=78)
     assert rooms.tune(torch.from_numpy(synth.room_like(2, 4096, 1901)).to(dev)) is False
+
+
+@pytest.mark.gpu
+def test_random_configurations_match_the_oracle(dev):
+    """150 random op configurations (fixed seed; tools/fuzz_gpu.py draws the same way, 2 800 of them in round 5): sizes
+    that are not multiples of a tile, one-cloud batches, anisotropic strides, 1 / 2 / 3 / 5-tap axes (filters of up to 64
+    taps), lattice / identical / isolated clouds, the models' and other channel shapes, fp32 and fp64, stateless and
+    cached -- neighbour counts exact, y / dX / dW within the op's tolerance of the oracle.  Where a lattice cloud's many
+    coincident points make the reference's own fp32 sums the looser side, both are judged against the exact sums over the
+    oracle's pair lists."""
+    rng = np.random.default_rng(20260929)
+    shapes = [(3, 9), (9, 9), (6, 9), (12, 9), (36, 13), (3, 3), (9, 3), (5, 7), (16, 16), (33, 20)]
+    kinds = ["modelnet", "room", "cube", "lattice", "vlattice", "identical", "isolated"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for it in range(150):
+        kind = kinds[rng.integers(len(kinds))]
+        ci, co = shapes[rng.integers(len(shapes))]
+        B = int(rng.integers(1, 5))
+        N = int(rng.choice([1, 2, 63, 64, 65, 100, 127, 129, 200, 500, 777, 1024, 1500, 2048, 2500]))
+        if kind == "identical" and N > 300:
+            N = 300
+        if ci * co > 300 and N > 600:
+            N = 600
+        f = tuple(int(v) for v in rng.choice([1, 2, 3, 3, 3, 5], size=3))
+        if f[0] * f[1] * f[2] > 64:
+            f = (3, 3, 3)
+        s = tuple(int(v) for v in rng.integers(1, 5, size=3)) if rng.random() < 0.4 else (int(rng.integers(1, 5)),) * 3
+        dt = np.float64 if rng.random() < 0.15 else np.float32
+        P, X, W, dY = make_case(kind, B, N, ci, co, f, seed=1000 + it, dtype=dt)
+        cache = None
+        if rng.random() < 0.5:
+            cache = op.NeighborCache(B, N, torch.float32 if dt == np.float32 else torch.float64, dev, slots=2,
+                                     max_taps=f[0] * f[1] * f[2], max_cin=ci, max_cout=co)
+        what = (it, kind, B, N, ci, co, f, s, np.dtype(dt).name, "cached" if cache is not None else "stateless")
+        cnt = op.neighbor_count(t(P), f, s, VOX).cpu().numpy()
+        y = op.conv3p(t(P), t(X), t(W), s, VOX, cache=cache).cpu().numpy()
+        dx, dw = op.conv3p_grad(t(dY), t(P), t(X), t(W), s, VOX, cache=cache)
+        dx, dw = dx.cpu().numpy(), dw.cpu().numpy()
+        assert np.array_equal(cnt, oracle.neighbor_count(P, f, s, VOX)), what
+        ry = oracle.forward(P, X, W, s, VOX)
+        rdx, rdw = oracle.backward(dY, P, X, W, s, VOX)
+        ty, tw = TOL[np.dtype(dt)]
+        if rel_err(y, ry) <= ty and rel_err(dx, rdx) <= ty and rel_err(dw, rdw) <= tw:
+            continue
+        assert dt == np.float32, what
+        dwe = 0.0
+        for b in range(B):
+            ye, dxe, dwb = exact_from_oracle_lists(P[b], X[b], W, dY[b], s, VOX)
+            assert rel_err(y[b], ye) <= ty and rel_err(dx[b], dxe) <= ty, what
+            dwe = dwe + dwb
+        assert rel_err(dw, dwe) <= tw or rel_err(dw, dwe) <= rel_err(rdw, dwe), what
