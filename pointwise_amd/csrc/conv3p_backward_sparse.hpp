@@ -105,6 +105,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
     // the list; wide layers: four ADJACENT lanes walk a centre's list together and split the output channels, so that
     // their pieces of one dY row and their common record form one access for the texture addresser
     constexpr bool kChSplit = CONV3P_SP_CHSPLIT && CIN >= 16;
+#ifndef CONV3P_SP_HALVES
+#define CONV3P_SP_HALVES 1   // developer A/B: 0 = tiles over the capacity take rounds by taps (every list walked once per round)
+#endif
+    constexpr bool kHalves = CONV3P_SP_HALVES && kChSplit && sizeof(T) == 4 && CIN >= 16;   // (needs phase C on the matrix cores)
     int cq = wave * 16 + (lane >> 2);
     uint32_t sub = lane & 3u, maxn = 4u;
     uint32_t *share = reinterpret_cast<uint32_t *>(soa);   // the wave's lane-sharing scratch (soa is the overflow path's)
@@ -160,11 +164,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
     }
     // ---- which (centre, tap) rows exist, and in which round each tap is handled.  Every wave runs the same scalar
     // bookkeeping over all taps (ballots + counts) and publishes the taps f == wave (mod 4): no serial section.
-    const uint32_t mybm = live && me.idx >= 0 ? bm_raw : 0u;   // lane = centre in every wave
-    {
+    const uint32_t mybm_all = live && me.idx >= 0 ? bm_raw : 0u;   // lane = centre in every wave
+    uint32_t mybm = mybm_all;                                      // ... restricted to the centres of the running half (below)
+    auto build_rows = [&](uint32_t bmv) {
         uint32_t base = 0, gbase = 0, nrounds = 1;
         for (int f = 0; f < st.ntap; ++f) {   // (ntap <= 32: host)
-            const bool has = (mybm >> f) & 1u;
+            const bool has = (bmv >> f) & 1u;
             const uint64_t m = __ballot(has);
             const uint32_t n = (uint32_t)__popcll(m);
             if (base + n > (uint32_t)cap) {
@@ -191,7 +196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
             rinfo[1] = 0;
             rinfo[1 + nrounds] = (uint32_t)st.ntap;
         }
-    }
+    };
+    build_rows(mybm);
     __syncthreads();
     if (!live) {   // (uniform) a workgroup past the last cloud: its grad_filter partial is summed like the others
         T *z = partials + (size_t)blockIdx.x * nw;
@@ -220,67 +226,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
             for (int e = threadIdx.x; e < n4; e += blockDim.x) G4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // ---- phase A of the wide layers (>= 16 inputs; 36 -> 13 of the scene-segmentation stack).  Four ADJACENT lanes work on
+    // one record and split the output channels (13: 4 + 4 + 4 + 1), so every lane owns its entries of G: nothing to merge
+    // across the lanes of a record.  The walk is bound by the CU's address units (a wave-level gather costs them 33-45
+    // cycles whatever its width, profiles/HISTORY.md), so records, populations and rows of G are fetched for FOUR steps at
+    // a time: sub-lane s of a centre loads record 4 k + s, its population and its row of G (one instruction each per
+    // four steps instead of one per step) and the four lanes pass them round by quad broadcasts (v_mov_dpp quad_perm);
+    // only the pieces of the dY rows are still one load per step -- 6 memory instructions per 4 steps instead of 12.
+    // Groups are pipelined over two named slots: the records of group k + 2 and the gathers of group k + 1 are in
+    // flight while group k is accumulated.
+    //   h < 0:  the whole tile, 16 centres per wave (tiles whose populated rows fit G; `t0 .. t1` = every tap)
+    //   h >= 0: the centres 32 h .. 32 h + 31, eight per wave, of a tile whose rows exceed the capacity.  Rounds by taps
+    //           walk every list once per round; split by CENTRES, a list is walked once: lanes 32-63 take the same
+    //           centres' ODD records while lanes 0-31 take the even ones.  Two records of one centre that meet on a row
+    //           of G in one step take turns, the even record first (a wave's LDS accesses execute in program order):
+    //           race-free, in a fixed order.
+    auto phase_A_wide = [&](int h, int t0, int t1) {
+        constexpr int CPL = (COUT + 3) / 4;                       // channels per sub-lane
+        const bool two = h >= 0;                                  // (uniform)
+        const uint32_t nstr = two ? 2u : 1u;
+        const uint32_t strm = two ? (uint32_t)lane >> 5 : 0u;
+        const int cqw = two ? 32 * h + 8 * wave + ((lane & 31) >> 2) : wave * 16 + (lane >> 2);
+        const uint32_t subw = (uint32_t)lane & 3u;
+        const uint64_t lt_w = cqw == 0 ? 0ull : (~0ull >> (64 - cqw));
+        const int c0 = (int)subw * CPL;
+        const int nc = COUT - c0 < 0 ? 0 : (COUT - c0 < CPL ? COUT - c0 : CPL);
+        constexpr int kShiftLast = 4 * CPL - COUT;                // the last piece is read from the row's end backwards
+        const int start = c0 < COUT - CPL ? c0 : COUT - CPL;
+        for (int g = 0; g < ngroups; ++g) {
+            const uint2 sg = qsegs[(tile_id * ngroups + g) * 64 + cqw];
+            const PairEntry *pe = pairs + sg.x;
+            PairEntry rec[2];
+            uint32_t fbv[2], row[2];
+            bool lv[2];
+            int cn[2];
+            T val[2][4][CPL];
+            auto own = [&](uint32_t k) { return strm + nstr * (4u * k + subw); };   // this lane's record of group k
+            auto ld_rec = [&](int sl, uint32_t k) {
+                const uint32_t i = own(k);
+                rec[sl] = pe[i < sg.y ? i : 0u];
+            };
+            auto gather = [&](int sl, uint32_t k) {
+                const uint32_t fb = code_bwd(rec[sl].code);
+                const bool l = own(k) < sg.y && code_fwd(rec[sl].code) != kNoTap && fb != kNoTap && (int)fb >= t0 && (int)fb < t1;
+                lv[sl] = l;
+                fbv[sl] = l ? fb : kTurnIdle;
+                row[sl] = slot_of(l ? fb : (uint32_t)t0, lt_w);
+                cn[sl] = cnt_cloud[l ? (size_t)rec[sl].cand * st.ntap + fb : (size_t)0];
+                const uint32_t cand = l ? rec[sl].cand : 0u;
+                RowLoader<T, CPL>::load(dy_cloud + (size_t)quad_bcast<0>(cand) * ld.dy + start, val[sl][0]);
+                RowLoader<T, CPL>::load(dy_cloud + (size_t)quad_bcast<1>(cand) * ld.dy + start, val[sl][1]);
+                RowLoader<T, CPL>::load(dy_cloud + (size_t)quad_bcast<2>(cand) * ld.dy + start, val[sl][2]);
+                RowLoader<T, CPL>::load(dy_cloud + (size_t)quad_bcast<3>(cand) * ld.dy + start, val[sl][3]);
+            };
+            auto accumulate = [&](int sl) {
+                const bool pend_own = lv[sl] & (cn[sl] != 0);                                   // .cpp:679
+                const uint32_t fb_own = pend_own ? fbv[sl] : kTurnIdle;
+                const T rcp_own = cn[sl] < 256 ? rinv[cn[sl] > 0 ? cn[sl] : 0] : (T)1 / (T)cn[sl];   // .cpp:692, :696
+                auto step = [&](auto uc) {
+                    constexpr int U = decltype(uc)::value;
+                    const uint32_t fb = quad_bcast<U>(fb_own);
+                    const bool pending = fb != kTurnIdle;
+                    const T rcpb = __builtin_bit_cast(T, quad_bcast<U>(__builtin_bit_cast(uint32_t, rcp_own)));
+                    T *grow = G + (size_t)quad_bcast<U>(row[sl]) * COUT + c0;
+                    T x[CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) x[c] = ((subw == 3u && c + kShiftLast < CPL) ? val[sl][U][(c + kShiftLast) % CPL] : val[sl][U][c]) * rcpb;
+                    bool second = false;
+                    if (two) {
+                        const uint32_t fb_other = (uint32_t)__shfl_xor((int)fb, 32);   // (every lane takes part: not under the && below)
+                        second = pending && strm == 1u && fb_other == fb;              // the even record has the row first
+                    }
+                    if (pending && !second) {
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c)
+                            if (c < nc) grow[c] += x[c];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    if (two && __any(second)) {
+                        if (second) {
+#pragma unroll
+                            for (int c = 0; c < CPL; ++c)
+                                if (c < nc) grow[c] += x[c];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    }
+                };
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 2>{});
+                step(std::integral_constant<int, 3>{});
+            };
+            ld_rec(0, 0u);
+            ld_rec(1, 1u);
+            __builtin_amdgcn_sched_barrier(0);
+            gather(0, 0u);
+            uint32_t k = 0;
+            bool more = true;
+            while (more) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!__any(strm + nstr * 4u * k < sg.y)) {
+                        more = false;
+                        break;
+                    }
+                    gather(j ^ 1, k + 1u);        // (its records were requested an iteration ago)
+                    ld_rec(j, k + 2u);            // (group k's records are no longer needed: its gathers are out)
+                    __builtin_amdgcn_sched_barrier(0);
+                    accumulate(j);
+                    k += 1u;
+                }
+            }
+        }
+    };
     auto phase_A = [&](int t0, int t1) {
         // ---- phase A
         if (CONV3P_SP_ABLATE & 1) {
         } else if (!overflow && kChSplit) {
-            // The four sub-lanes of a centre walk its list TOGETHER and split the output channels (13: 4 + 4 + 4 + 1;
-            // 9: 3 + 3 + 3): every lane owns its G entries, so no two lanes ever meet on an address and nothing has
-            // to be merged across lanes (measured on 36 -> 13, rooms, stride 1: the lane-swap merge of the
-            // record-split walk below was 180 of phase A's 305 us -- with ~80 pairs over ~12 taps per centre its
-            // sub-lanes met on a tap in nearly every step).  Record and count loads are shared by the four lanes
-            // (one address), the dY row is read as one <= 4-element piece per lane.
-            constexpr int CPL = (COUT + 3) / 4;                       // channels per sub-lane
-            const int c0 = sub * CPL;
-            const int nc = COUT - c0 < 0 ? 0 : (COUT - c0 < CPL ? COUT - c0 : CPL);
-            constexpr int kShiftLast = 4 * CPL - COUT;                // the last piece is read from the row's end backwards
-            const int start = c0 < COUT - CPL ? c0 : COUT - CPL;
-            for (int g = 0; g < ngroups; ++g) {
-                const uint2 sg = g == 0 ? sg0 : qsegs[(tile_id * ngroups + g) * 64 + cq];
-                const PairEntry *pe = pairs + sg.x;
-                PairEntry rec[kDepth];
-                bool lv[kDepth];
-                int cn[kDepth];
-                uint32_t row[kDepth];
-                T val[kDepth][CPL];
-                auto ld_rec = [&](uint32_t i) { return pe[i < sg.y ? i : 0u]; };
-                auto gather = [&](int sl, uint32_t i) {
-                    const uint32_t fb = code_bwd(rec[sl].code);
-                    lv[sl] = i < sg.y && code_fwd(rec[sl].code) != kNoTap && fb != kNoTap && (int)fb >= t0 && (int)fb < t1;
-                    row[sl] = slot_of(lv[sl] ? fb : (uint32_t)t0, lt_cq);
-                    cn[sl] = cnt_cloud[lv[sl] ? (size_t)rec[sl].cand * st.ntap + fb : (size_t)0];
-                    RowLoader<T, CPL>::load(dy_cloud + (size_t)(lv[sl] ? rec[sl].cand : 0u) * ld.dy + start, val[sl]);
-                };
-#pragma unroll
-                for (int sl = 0; sl < kDepth - 1; ++sl) rec[sl] = g == 0 ? rec0[sl] : ld_rec((uint32_t)sl);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sl = 0; sl < kDepth - 2; ++sl) gather(sl, (uint32_t)sl);
-                uint32_t i = 0;
-                bool more = true;
-                while (more) {
-#pragma unroll
-                    for (int j = 0; j < kDepth; ++j) {
-                        if (!__any(i < sg.y)) {
-                            more = false;
-                            break;
-                        }
-                        rec[(j + kDepth - 1) % kDepth] = ld_rec(i + (kDepth - 1));
-                        gather((j + kDepth - 2) % kDepth, i + (kDepth - 2));
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (lv[j] & (cn[j] != 0)) {                                               // .cpp:679
-                            const T rcpb = cn[j] < 256 ? rinv[cn[j]] : (T)1 / (T)cn[j];            // .cpp:692, :696
-                            T *grow = G + (size_t)row[j] * COUT + c0;
-#pragma unroll
-                            for (int c = 0; c < CPL; ++c) {
-                                const T x = (sub == 3 && c + kShiftLast < CPL) ? val[j][(c + kShiftLast) % CPL] : val[j][c];
-                                if (c < nc) grow[c] += x * rcpb;
-                            }
-                        }
-                        i += 1;
-                    }
-                }
-            }
+            phase_A_wide(-1, t0, t1);
         } else if (!overflow) {
             for (int g = 0; g < ngroups; ++g) {
                 LaneShare lsg = ls0;
@@ -388,7 +451,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
             }, cmin != nullptr ? &win : nullptr);
         }
     };
-    auto phase_B = [&](int t0, int t1) {
+    auto phase_B = [&](int t0, int t1, bool accumulate = false) {
         T *slot_out = partials + (size_t)blockIdx.x * nw;
         // ---- phase B: dW[f'][k][c] = sum over the tap's slots of X[j(slot)][k] * G[slot][c].  fp32: on the matrix cores
         // (v_mfma_f32_16x16x4_f32, an exact fmaf chain: deterministic), wave w takes the round's taps f' == w (mod 4);
@@ -439,7 +502,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int k = kb * 16 + 4 * l4 + rr;
-                        if (k < CIN && l15 < COUT) partial_store(&so[((size_t)f * CIN + k) * COUT + l15], acc0[kb][rr] + acc1[kb][rr]);
+                        if (k < CIN && l15 < COUT) {
+                            // (second half of a tile split by centres: this lane wrote the first half's sum itself)
+                            float *dst = &so[((size_t)f * CIN + k) * COUT + l15];
+                            const float sum = acc0[kb][rr] + acc1[kb][rr];
+                            partial_store(dst, accumulate ? *dst + sum : sum);
+                        }
                     }
             }
         } else {
@@ -521,7 +589,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
                     if (k < CIN) red[((size_t)wave * CIN + k) * 64 + 16 * mb + 4 * (lane >> 4) + r] = acc[mb][kb][r];
                 }
     };
-    auto phase_C_mfma = [&](int t0, int t1, f32x4 (&accC)[4][NKC]) {
+    auto phase_C_mfma = [&](int t0, int t1, f32x4 (&accC)[4][NKC], int half = -1) {   // half >= 0: only its centres have rows
         if constexpr (kMfmaC) {
             const int l15 = lane & 15, l4 = lane >> 4;
             // tap sets and lower-centre masks of the four centres this lane feeds into the A operand (computed here, not
@@ -574,6 +642,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
                     }
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) {
+                        if (half >= 0 && (mb >> 1) != half) continue;   // (uniform)
                         float a = Gf[(size_t)slot[mb] * COUT + (c < COUT ? c : 0)];
                         a = (has[mb] && c < COUT) ? a : 0.0f;
 #pragma unroll
@@ -623,6 +692,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
             phase_C(0, st.ntap, dx);
 #endif
             SDBG()
+        }
+    } else if (kHalves && !overflow) {
+        // (uniform) more rows than G holds: the two halves of the centres one after the other, each with rows of its own
+        if constexpr (kHalves) {
+            f32x4 accR[4][NKC];
+            zero_acc(accR);
+#if CONV3P_SP_ABLATE & 128
+            long long ra_ = 0, rb_ = 0, rc_ = 0, rs_ = 0, t_;
+            int nrs_ = 0;
+#define HDBG(v) { __builtin_amdgcn_s_waitcnt(0); const long long n_ = wall_clock64(); v += n_ - t_; t_ = n_; }
+            __builtin_amdgcn_s_waitcnt(0); t_ = wall_clock64();
+#else
+#define HDBG(v)
+#endif
+            for (int h = 0; h < 2; ++h) {
+                __syncthreads();   // the row bookkeeping and G of the previous half (of the whole tile) are no longer read
+                mybm = (lane >> 5) == h ? mybm_all : 0u;
+                build_rows(mybm);
+                __syncthreads();
+                const int nr = (int)rinfo[0];
+                for (int r = 0; r < nr; ++r) {
+                    const int t0 = (int)rinfo[1 + r], t1 = (int)rinfo[2 + r];
+                    if (r > 0) __syncthreads();
+                    zero_G(t1);
+                    __syncthreads();
+                    HDBG(rs_)
+                    phase_A_wide(h, t0, t1);
+                    HDBG(ra_)
+                    __syncthreads();
+                    HDBG(rs_)
+                    phase_B(t0, t1, h > 0);
+                    HDBG(rb_)
+                    phase_C_mfma(t0, t1, accR, h);
+                    HDBG(rc_)
+#if CONV3P_SP_ABLATE & 128
+                    ++nrs_;
+#endif
+                }
+            }
+#if CONV3P_SP_ABLATE & 128
+            if (lane == 0 && (blockIdx.x % 211) == 7)
+                printf("bsp<%d,%d> wg %d wave %d: rounds %d  prologue %lld  syncs %lld  phaseA %lld  B %lld  C %lld\n", CIN, COUT, (int)blockIdx.x, wave,
+                       nrs_, st_[1] - st_[0], rs_, ra_, rb_, rc_);
+#endif
+            __syncthreads();   // red aliases G: every wave is done with its last phase C
+            red_from_acc(accR);
+            red_written = true;
         }
     } else {
 #pragma unroll

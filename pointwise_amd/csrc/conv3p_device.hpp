@@ -35,6 +35,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace conv3p {
 
@@ -639,6 +640,11 @@ __device__ __forceinline__ LaneWalk lane_walk(const LaneShare &ls, bool blocked)
         w.end = ls.seg.y;
     }
     return w;
+}
+// value of lane U of this lane's quad (four adjacent lanes) in all four of them: v_mov_dpp quad_perm:[U,U,U,U]
+template <int U> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, U * 0x55, 0xF, 0xF, true);
 }
 // Turn of this lane among the lanes of its centre (the r lanes just below it belong to the same centre) that want the
 // same tap in this step: the number of those lower lanes whose tap equals this lane's.  `tap` = kTurnIdle for a lane
