@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
                 lv[sl] = l;
                 fbv[sl] = l ? fb : kTurnIdle;
                 row[sl] = slot_of(l ? fb : (uint32_t)t0, lt_w);
-                cn[sl] = cnt_cloud[l ? (size_t)rec[sl].cand * st.ntap + fb : (size_t)0];
-                const uint32_t cand = l ? rec[sl].cand : 0u;
+                cn[sl] = cnt_cloud[(l && !(CONV3P_SP_ABLATE & 2048)) ? (size_t)rec[sl].cand * st.ntap + fb : (size_t)0];
+                const uint32_t cand = (l && !(CONV3P_SP_ABLATE & 2048)) ? rec[sl].cand : 0u;   // (2048: developer timing, every dY piece an L1 hit)
                 RowLoader<T, CPL>::load(dy_cloud + (size_t)quad_bcast<0>(cand) * ld.dy + start, val[sl][0]);
                 RowLoader<T, CPL>::load(dy_cloud + (size_t)quad_bcast<1>(cand) * ld.dy + start, val[sl][1]);
                 RowLoader<T, CPL>::load(dy_cloud + (size_t)quad_bcast<2>(cand) * ld.dy + start, val[sl][2]);
@@ -283,39 +283,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
                 const bool pend_own = lv[sl] & (cn[sl] != 0);                                   // .cpp:679
                 const uint32_t fb_own = pend_own ? fbv[sl] : kTurnIdle;
                 const T rcp_own = cn[sl] < 256 ? rinv[cn[sl] > 0 ? cn[sl] : 0] : (T)1 / (T)cn[sl];   // .cpp:692, :696
-                auto step = [&](auto uc) {
+                // the group's four records of this centre: row of G (a value no other step has where the step is idle) and
+                // this lane's piece of dY / count
+                uint32_t rw[4];
+                bool pd[4];
+                T x[4][CPL];
+                auto prep = [&](auto uc) {
                     constexpr int U = decltype(uc)::value;
-                    const uint32_t fb = quad_bcast<U>(fb_own);
-                    const bool pending = fb != kTurnIdle;
+                    pd[U] = quad_bcast<U>(fb_own) != kTurnIdle;
+                    rw[U] = pd[U] ? quad_bcast<U>(row[sl]) : 0xFFFFFFF0u + (uint32_t)U;
                     const T rcpb = __builtin_bit_cast(T, quad_bcast<U>(__builtin_bit_cast(uint32_t, rcp_own)));
-                    T *grow = G + (size_t)quad_bcast<U>(row[sl]) * COUT + c0;
-                    T x[CPL];
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) x[c] = ((subw == 3u && c + kShiftLast < CPL) ? val[sl][U][(c + kShiftLast) % CPL] : val[sl][U][c]) * rcpb;
-                    bool second = false;
-                    if (two) {
-                        const uint32_t fb_other = (uint32_t)__shfl_xor((int)fb, 32);   // (every lane takes part: not under the && below)
-                        second = pending && strm == 1u && fb_other == fb;              // the even record has the row first
-                    }
-                    if (pending && !second) {
+                    for (int c = 0; c < CPL; ++c) x[U][c] = ((subw == 3u && c + kShiftLast < CPL) ? val[sl][U][(c + kShiftLast) % CPL] : val[sl][U][c]) * rcpb;
+                };
+                prep(std::integral_constant<int, 0>{});
+                prep(std::integral_constant<int, 1>{});
+                prep(std::integral_constant<int, 2>{});
+                prep(std::integral_constant<int, 3>{});
+                // ONE LDS round trip for the four steps (it was one per step, each waiting for the one before: 100 of the
+                // heaviest tile's 153 us, profiles/r05_wide_phaseA.txt): the four rows are read together, the sums are formed
+                // in record order in registers -- a step whose row an earlier step of the group has already updated takes
+                // that step's value, not the stale one read -- and written back in order (the last write of a row holds
+                // its total).  Same additions in the same order as the step-by-step form.
+                auto rmw = [&]() {
+                    if (CONV3P_SP_ABLATE & 1024) {          // developer timing: no read-modify-write at all
 #pragma unroll
-                        for (int c = 0; c < CPL; ++c)
-                            if (c < nc) grow[c] += x[c];
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int c = 0; c < CPL; ++c) asm volatile("" :: "v"(x[u][c]));
+                        return;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    if (two && __any(second)) {
-                        if (second) {
+                    T g[4][CPL];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const T *gr = G + (size_t)(pd[u] ? rw[u] : 0u) * COUT + c0;   // (idle step: some valid row, value unused)
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) g[u][c] = gr[c < nc ? c : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int v = 0; v < u; ++v) {       // (ascending: the latest earlier step on the same row wins)
+                            const bool same = rw[v] == rw[u];
+#pragma unroll
+                            for (int c = 0; c < CPL; ++c) g[u][c] = same ? g[v][c] : g[u][c];
+                        }
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) g[u][c] += x[u][c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (pd[u]) {
+                            T *gw = G + (size_t)rw[u] * COUT + c0;
 #pragma unroll
                             for (int c = 0; c < CPL; ++c)
-                                if (c < nc) grow[c] += x[c];
+                                if (c < nc) gw[c] = g[u][c];
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    }
                 };
-                step(std::integral_constant<int, 0>{});
-                step(std::integral_constant<int, 1>{});
-                step(std::integral_constant<int, 2>{});
-                step(std::integral_constant<int, 3>{});
+                if (!two) {
+                    rmw();
+                } else {
+                    // the even records' group first, then the odd records': the two may meet on a row
+                    if (strm == 0u) rmw();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (strm == 1u) rmw();
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             };
             ld_rec(0, 0u);
             ld_rec(1, 1u);
@@ -472,6 +505,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
                     acc0[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
                     acc1[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+                // (second half of a tile split by centres: this lane wrote the first half's sums itself; they are requested now
+                // and arrive under the tap's products)
+                float old[NKB][4];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int k = kb * 16 + 4 * l4 + rr;
+                        old[kb][rr] = accumulate ? so[((size_t)f * CIN + (k < CIN ? k : 0)) * COUT + (l15 < COUT ? l15 : 0)] : 0.0f;
+                    }
                 for (int s0 = 0; s0 < n; s0 += 16) {   // 16 slots per iteration: lane group l4 takes slots s0 + 4 l4 .. + 3
                     const int sb = s0 + 4 * l4;
                     const uint32_t cj4 = *reinterpret_cast<const uint32_t *>(sj + ti.gbase + (sb < n ? sb : 0));   // four centres
@@ -503,10 +546,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
                     for (int rr = 0; rr < 4; ++rr) {
                         const int k = kb * 16 + 4 * l4 + rr;
                         if (k < CIN && l15 < COUT) {
-                            // (second half of a tile split by centres: this lane wrote the first half's sum itself)
-                            float *dst = &so[((size_t)f * CIN + k) * COUT + l15];
                             const float sum = acc0[kb][rr] + acc1[kb][rr];
-                            partial_store(dst, accumulate ? *dst + sum : sum);
+                            partial_store(&so[((size_t)f * CIN + k) * COUT + l15], accumulate ? old[kb][rr] + sum : sum);
                         }
                     }
             }
@@ -602,52 +643,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
                 bmc[mb] = (uint32_t)__shfl((int)mybm, ci);
                 ltc[mb] = ci == 0 ? 0ull : (~0ull >> (64 - ci));
             }
-            float *wb = soa;                                   // [CIN][4] slice of W[f'] (the wave's scratch: 192 floats)
-            static_assert(!kMfmaC || CIN * 4 <= 192, "phase C: the staged filter slice must fit the wave's scratch");
             const float *Gf = reinterpret_cast<const float *>(G);
             const float *ff = reinterpret_cast<const float *>(filter);
             constexpr int NCS = (COUT + 3) / 4;
-            for (int f = t0 + ((wave - t0) & (kWavesPerBlock - 1)); f < ((CONV3P_SP_ABLATE & 4) ? t0 : t1); f += kWavesPerBlock) {
-                const TapInfo ti = tapinfo[f];
-                const uint64_t m = ((uint64_t)ti.mask_hi << 32) | ti.mask_lo;
-                if (m == 0ull) continue;                       // (uniform)
-                uint32_t slot[4];
-                bool has[4];
+            // B operand of (tap, channel slice cs, input block kb): B[kk = l4][n = l15] = W[f'][16 kb + l15][4 cs + l4], read
+            // straight from the caller's filter (50 KB for 36 -> 13: cache resident) into registers, the NEXT tap's twelve
+            // values requested before this tap's products (two named slots).  (Round 5, first form: a [Cin][4] slice staged
+            // in the wave's scratch per (tap, cs) -- one exposed memory latency each, 46 us of the heaviest tile's 260.)
+            float bw[2][NCS][NKC];
+            auto ld_w = [&](int sl, int f) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    has[mb] = (bmc[mb] >> f) & 1u;
-                    slot[mb] = has[mb] ? ti.base + (uint32_t)__popcll(m & ltc[mb]) : 0u;
-                }
-#pragma unroll
-                for (int cs = 0; cs < NCS; ++cs) {
-                    // W[f'][k = lane][4 cs .. 4 cs + 3]: the last slice is read from the row's end backwards and shifted
-                    const int c0 = 4 * cs;
-                    const int start = c0 + 4 <= COUT ? c0 : COUT - 4, sh = c0 - start;
-                    const int krow = lane < CIN ? lane : 0;
-                    const float4_a4 wv = *reinterpret_cast<const float4_a4 *>(ff + ((size_t)f * CIN + krow) * COUT + start);
-                    const float w4[4] = {wv.x, wv.y, wv.z, wv.w};
-                    __builtin_amdgcn_wave_barrier();           // the previous slice's readers are done (program order)
-                    if (lane < CIN) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) wb[lane * 4 + u] = (c0 + u < COUT) ? w4[(u + sh) & 3] : 0.0f;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const int c = c0 + l4;
-                    float bv[NKC];
+                for (int cs = 0; cs < NCS; ++cs)
 #pragma unroll
                     for (int kb = 0; kb < NKC; ++kb) {
-                        const int k = 16 * kb + l15;
-                        bv[kb] = wb[(k < CIN ? k : 0) * 4 + l4];
-                        bv[kb] = k < CIN ? bv[kb] : 0.0f;
+                        const int k = 16 * kb + l15, c = 4 * cs + l4;
+                        const bool ok = k < CIN && c < COUT;
+                        bw[sl][cs][kb] = ff[((size_t)f * CIN + (ok ? k : 0)) * COUT + (ok ? c : 0)];
                     }
+            };
+            const int tend = (CONV3P_SP_ABLATE & 4) ? t0 : t1;
+            int f = t0 + ((wave - t0) & (kWavesPerBlock - 1));
+            if (f < tend) ld_w(0, f);
+            bool more = f < tend;
+            while (more) {
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        if (half >= 0 && (mb >> 1) != half) continue;   // (uniform)
-                        float a = Gf[(size_t)slot[mb] * COUT + (c < COUT ? c : 0)];
-                        a = (has[mb] && c < COUT) ? a : 0.0f;
-#pragma unroll
-                        for (int kb = 0; kb < NKC; ++kb) accC[mb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[kb], accC[mb][kb], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if (f >= tend) {
+                        more = false;
+                        break;
                     }
+                    if (f + kWavesPerBlock < tend) ld_w(j ^ 1, f + kWavesPerBlock);   // (uniform)
+                    const TapInfo ti = tapinfo[f];
+                    const uint64_t m = ((uint64_t)ti.mask_hi << 32) | ti.mask_lo;
+                    if (m != 0ull) {                               // (uniform)
+                        uint32_t slot[4];
+                        bool has[4];
+#pragma unroll
+                        for (int mb = 0; mb < 4; ++mb) {
+                            has[mb] = (bmc[mb] >> f) & 1u;
+                            slot[mb] = has[mb] ? ti.base + (uint32_t)__popcll(m & ltc[mb]) : 0u;
+                        }
+#pragma unroll
+                        for (int cs = 0; cs < NCS; ++cs) {
+                            const int c = 4 * cs + l4;
+                            float bv[NKC];
+#pragma unroll
+                            for (int kb = 0; kb < NKC; ++kb) bv[kb] = (16 * kb + l15 < CIN && c < COUT) ? bw[j][cs][kb] : 0.0f;
+#pragma unroll
+                            for (int mb = 0; mb < 4; ++mb) {
+                                if (half >= 0 && (mb >> 1) != half) continue;   // (uniform)
+                                float a = Gf[(size_t)slot[mb] * COUT + (c < COUT ? c : 0)];
+                                a = (has[mb] && c < COUT) ? a : 0.0f;
+#pragma unroll
+                                for (int kb = 0; kb < NKC; ++kb) accC[mb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[kb], accC[mb][kb], 0, 0, 0);
+                            }
+                        }
+                    }
+                    f += kWavesPerBlock;
                 }
             }
         }
