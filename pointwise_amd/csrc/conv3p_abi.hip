@@ -177,7 +177,8 @@ template <typename T> struct Layout {
         unsigned long long *built_tag;
         int32_t *count, *tcount;   // populations: original-index order (B,N,F) / tile-major [tile][F][64]
         uint2 *segs, *qsegs;
-        uint32_t *qbm;             // [B][ntiles][64] backward taps each centre's list holds (bit f'; <= 32 taps)
+        uint32_t *qbm;             // [B][ntiles][64] backward taps each centre's list holds (bit f' of taps 0 .. 31)
+        uint32_t *qbm_hi;          // ... taps 32 .. 63 (caches / workspaces for filters of more than 32 taps; else nullptr)
         uint32_t *sched;           // [8][ceil(B / 8) * ntiles] launch order of the tiles per XCD (tile_sched_kernel)
         uint32_t *regime;          // [1] 1: short pair lists on average (tile_sched_kernel), see SchedJob
         PairEntry *pairs;
@@ -238,7 +239,8 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
         S.tcount = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)B * ntiles * kTile * ntap_max));
         S.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups));
         S.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups * 64));
-        S.qbm = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * ntiles * 64));
+        S.qbm = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * ntiles * 64 * (ntap_max > 32 ? 2 : 1)));
+        S.qbm_hi = ntap_max > 32 && S.qbm != nullptr ? S.qbm + (size_t)B * ntiles * 64 : nullptr;
         S.sched = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * 8 * (size_t)((B + 7) / 8) * ntiles));
         S.regime = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t)));
         S.pairs = reinterpret_cast<PairEntry *>(take(sizeof(PairEntry) * (size_t)B * ppc));
@@ -533,6 +535,7 @@ template <typename T> FusedJob<T> make_fused_job(const Call<T> &c)
     j.segs = S.segs;
     j.qsegs = S.qsegs;
     j.qbm = S.qbm;
+    j.qbm_hi = S.qbm_hi;
     for (int a = 0; a < 3; ++a)
         for (int k = 0; k < kFMaxExt; ++k)
             j.clo[a][k] = (float)(((double)k * c.st.step[a] - (double)c.st.full[a] * 0.5) * (double)kFR);
@@ -612,6 +615,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
             j.segs = nullptr;
             j.qsegs = nullptr;
             j.qbm = nullptr;
+            j.qbm_hi = nullptr;
             return launch_fused<T>(c, fj, sj, 1, /*schedule=*/false);
         }
         const int nj = add_companions<T>(c, fj, sj, 1);
@@ -628,7 +632,7 @@ template <typename T> int run_search(const Call<T> &c, int32_t *count, bool with
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), lds, c.s, c.L.pts, c.L.boxes, st, d.N, d.ntiles,
                                c.L.gtiles, c.L.ngroups, bm, count, with_pairs ? S.pairs : nullptr, c.cc, S.segs, S.qsegs,
-                               cmin, with_pairs ? S.tcount : nullptr, with_pairs ? S.qbm : nullptr);
+                               cmin, with_pairs ? S.tcount : nullptr, with_pairs ? S.qbm : nullptr, with_pairs ? S.qbm_hi : nullptr);
         };
         if (st.window) launch(search_kernel<T, true>, c.L.cmin);
         else launch(search_kernel<T, false>, static_cast<const T *>(nullptr));
@@ -756,7 +760,7 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
 // four (else three, else two) workgroups per CU; 0: use backward_kernel's dense G.
 template <typename T> int sparse_cap(const Stencil<T> &st, int cin, int cout, size_t &lds)
 {
-    if (st.ntap > 32 || cin < 1 || cout < 1 || cout > 16) return 0;   // (phase B holds the output channels in one 16-wide block)
+    if (st.ntap > 64 || (st.ntap > 32 && cin >= 16) || cin < 1 || cout < 1 || cout > 16) return 0;   // (phase B holds the output channels in one 16-wide block; 33 .. 64 taps: the narrow layers' 64-bit tap sets)
     // Undilated stencils populate a third of a centre's taps and more (adjacent cells: 9 of 27 on the ModelNet-shaped
     // clouds, 650-850 rows per tile): their tiles would take two rounds, each walking the pair lists again
     // (measured: 3 -> 9 stride 1 at the cfg2 size 63.8 us against 49.5 us dense).  Dilated ones: 210-450 rows.
@@ -803,13 +807,20 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
         if (cap > 0) {
             const BlockMap bm = make_blockmap(d);
             Scope sc(K_BACKWARD, c.s);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(backward_sparse_kernel<T, CI, CO>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
-            hipLaunchKernelGGL((backward_sparse_kernel<T, CI, CO>), dim3(grid_of(bm)), dim3(256), slds, c.s, c.L.pts, c.L.boxes,
-                               S.count, S.pairs, S.segs, S.qsegs, S.qbm, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
-                               bm, grad_input, partials ? partials : c.L.partials, (c.act ? 1 : 0) | (c.accum ? 2 : 0), c.addend,
-                               st.window ? c.L.cmin : nullptr, c.ld, cap, sched_of(S),
-                               by_regime ? S.regime : static_cast<const uint32_t *>(nullptr));
+            auto go = [&](auto kern) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);
+                hipLaunchKernelGGL(kern, dim3(grid_of(bm)), dim3(256), slds, c.s, c.L.pts, c.L.boxes,
+                                   S.count, S.pairs, S.segs, S.qsegs, S.qbm, S.qbm_hi, grad_out, input, filter, st, d.N, d.ntiles, c.L.ngroups,
+                                   bm, grad_input, partials ? partials : c.L.partials, (c.act ? 1 : 0) | (c.accum ? 2 : 0), c.addend,
+                                   st.window ? c.L.cmin : nullptr, c.ld, cap, sched_of(S),
+                                   by_regime ? S.regime : static_cast<const uint32_t *>(nullptr));
+            };
+            if constexpr (CI < 16) {
+                if (st.ntap > 32) go(backward_sparse_kernel<T, CI, CO, true>);   // 64-bit tap sets
+                else go(backward_sparse_kernel<T, CI, CO, false>);
+            } else {
+                go(backward_sparse_kernel<T, CI, CO, false>);
+            }
             if (!by_regime) return hip_ok();
             regime = S.regime;
         }
@@ -1628,6 +1639,7 @@ int prepare_multi_impl(const T *points, const int32_t *strides, int K, T voxel, 
         j.segs = S.segs;
         j.qsegs = S.qsegs;
         j.qbm = S.qbm;
+        j.qbm_hi = S.qbm_hi;
         sjobs.job[njobs - 1] = make_sched_job(c, c.slot, true);
     }
     if (njobs == 0) return CONV3P_OK;

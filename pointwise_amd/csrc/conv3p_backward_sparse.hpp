@@ -51,9 +51,11 @@ struct __attribute__((aligned(16))) TapInfo {
 
 // LDS of the sparse kernel apart from G [cap][Cout]:
 // tapmap | tapinfo[32] | rounds | qorig | slot -> centre map u8[64 * 32] | rinv | xt | soa     (red aliases G)
+// (tap tables for 32 taps, or 64 for filters of 33 .. 64 taps: the kernel's BIG instantiation)
 template <typename T> __host__ __device__ inline size_t sparse_fixed_lds(int maxfull, int ntap, int cin, int cout)
 {
-    return (((size_t)3 * maxfull * 2 + 15) & ~(size_t)15) + 32 * sizeof(TapInfo) + 64 * 4 + 256 + 2048 +
+    const size_t maxt = ntap > 32 ? 64 : 32;
+    return (((size_t)3 * maxfull * 2 + 15) & ~(size_t)15) + maxt * sizeof(TapInfo) + (maxt + 32) * 4 + 256 + 64 * maxt +
            ((256 * sizeof(T) + 15) & ~(size_t)15) + (((size_t)64 * cin * sizeof(T) + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * 192 * 4;
 }
 // G must also hold the final cross-wave sum [4][Cin][64]
@@ -62,13 +64,13 @@ template <typename T> __host__ __device__ inline size_t sparse_min_rows(int cin,
     return ((size_t)kWavesPerBlock * cin * 64 + cout - 1) / cout;
 }
 
-template <typename T, int CIN, int COUT>
+template <typename T, int CIN, int COUT, bool BIG = false>   // BIG: filters of 33 .. 64 taps (64-bit tap sets; narrow layers only)
 // (four waves per SIMD -- four workgroups per CU -- for the models' 3- and 9-input layers; 6 and 12 inputs, SceneNN's first
-// layer, which only gets here when dilated, would spill 2 / 16 registers under that cap)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 || CIN == 9) ? 4 : 2))) void backward_sparse_kernel(
+// layer, which only gets here when dilated, would spill 2 / 16 registers under that cap; so would the 64-bit tap sets of BIG)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (CIN == 3 || CIN == 9)) ? 4 : 2))) void backward_sparse_kernel(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
-    const uint32_t *__restrict__ qbm, const T *__restrict__ grad_out, const T *__restrict__ input,
+    const uint32_t *__restrict__ qbm, const uint32_t *__restrict__ qbm_hi, const T *__restrict__ grad_out, const T *__restrict__ input,
     const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, BlockMap bm, T *__restrict__ grad_input,
     T *__restrict__ partials, int act, const T *__restrict__ addend, const T *__restrict__ cmin, RowLd ld,
     int cap,   // G rows (slots) the LDS allocation holds; >= 64, so every tap fits a round of its own
@@ -80,14 +82,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
+    constexpr int kMaxT = BIG ? 64 : 32;                          // taps the tables hold
+    using BM = std::conditional_t<BIG, uint64_t, uint32_t>;       // set of backward taps of a centre
+    static_assert(!BIG || CIN < 16, "64-bit tap sets: narrow layers only (phase C of the wide ones shuffles 32-bit sets)");
     TapInfo *tapinfo = reinterpret_cast<TapInfo *>(smem + off);
-    off += 32 * sizeof(TapInfo);
-    uint32_t *rinfo = reinterpret_cast<uint32_t *>(smem + off);   // [0] rounds, [1 + r] first tap of round r, ... (<= 33 entries)
-    off += 64 * 4;
+    off += kMaxT * sizeof(TapInfo);
+    uint32_t *rinfo = reinterpret_cast<uint32_t *>(smem + off);   // [0] rounds, [1 + r] first tap of round r, ... (<= taps + 2 entries)
+    off += (kMaxT + 32) * 4;
     int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
     off += 256;
     uint8_t *sj = reinterpret_cast<uint8_t *>(smem + off);        // centre of every (tap, slot), taps ascending
-    off += 2048;
+    off += 64 * kMaxT;
     T *rinv = reinterpret_cast<T *>(smem + off);                  // rinv[n] = 1 / (T)n for n < 256
     off += align16(256 * sizeof(T));
     const size_t nw = (size_t)st.ntap * CIN * COUT;
@@ -132,7 +137,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
     const size_t tile_id = (size_t)(live ? b : 0) * ntiles + (live ? qt : 0);
     // loads that need nothing from LDS go out now, under the prologue: the tile's tap sets, its segment records (is
     // the tile's pair list complete?), this lane's centre segment and the first records of its list
-    const uint32_t bm_raw = qbm[tile_id * 64 + lane];
+    BM bm_raw = qbm[tile_id * 64 + lane];
+    if constexpr (BIG) bm_raw |= (BM)qbm_hi[tile_id * 64 + lane] << 32;
     bool overflow = false;
     for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
     LaneShare ls0;
@@ -164,11 +170,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
     }
     // ---- which (centre, tap) rows exist, and in which round each tap is handled.  Every wave runs the same scalar
     // bookkeeping over all taps (ballots + counts) and publishes the taps f == wave (mod 4): no serial section.
-    const uint32_t mybm_all = live && me.idx >= 0 ? bm_raw : 0u;   // lane = centre in every wave
-    uint32_t mybm = mybm_all;                                      // ... restricted to the centres of the running half (below)
-    auto build_rows = [&](uint32_t bmv) {
+    const BM mybm_all = live && me.idx >= 0 ? bm_raw : (BM)0;     // lane = centre in every wave
+    BM mybm = mybm_all;                                            // ... restricted to the centres of the running half (below)
+    auto build_rows = [&](BM bmv) {
         uint32_t base = 0, gbase = 0, nrounds = 1;
-        for (int f = 0; f < st.ntap; ++f) {   // (ntap <= 32: host)
+        for (int f = 0; f < st.ntap; ++f) {   // (ntap <= kMaxT: host)
             const bool has = (bmv >> f) & 1u;
             const uint64_t m = __ballot(has);
             const uint32_t n = (uint32_t)__popcll(m);
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CIN == 3 |
 #endif
             for (int h = 0; h < 2; ++h) {
                 __syncthreads();   // the row bookkeeping and G of the previous half (of the whole tile) are no longer read
-                mybm = (lane >> 5) == h ? mybm_all : 0u;
+                mybm = (lane >> 5) == h ? mybm_all : (BM)0;
                 build_rows(mybm);
                 __syncthreads();
                 const int nr = (int)rinfo[0];

@@ -456,10 +456,11 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
                                             PairEntry *__restrict__ pairs, const CacheCtl &cc,
                                             uint2 *__restrict__ segs, uint2 *__restrict__ qsegs,
                                             const T *__restrict__ cmin, int32_t *__restrict__ tcount,
-                                            uint32_t *__restrict__ qbm)   // [tile][64] set of backward taps of every centre's list (<= 32 taps)
+                                            uint32_t *__restrict__ qbm,   // [tile][64] set of backward taps of every centre's list: taps 0 .. 31
+                                            uint32_t *__restrict__ qbm_hi = nullptr)   // ... taps 32 .. 63 (filters of 33 .. 64 taps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t bmk[64];   // backward taps met by each centre of the tile (bit f'), see backward_sparse_kernel
+    __shared__ uint32_t bmk[128];   // backward taps met by each centre of the tile (bit f' & 31 of word [f' >> 5][centre]), see backward_sparse_kernel
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
@@ -486,8 +487,8 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
     if (pairs != nullptr && slot_valid(cc, b)) return;   // this cloud's lists are current (uniform)
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
-    if (threadIdx.x < 64) bmk[threadIdx.x] = 0;
-    const bool want_bm = qbm != nullptr && st.ntap <= 32;
+    if (threadIdx.x < 128) bmk[threadIdx.x] = 0;
+    const bool want_bm = qbm != nullptr && (st.ntap <= 32 || (st.ntap <= 64 && qbm_hi != nullptr));
     const uint32_t cap = cc.pairs_per_cloud;
     const uint32_t region = (uint32_t)b * cap;   // first pair slot of this cloud's region
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
@@ -602,7 +603,7 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
                             fwd = (uint32_t)((tz * st.ext[1] + ty) * st.ext[0] + tx);           // .cpp:290
                             atomicAdd(&cnt[fwd * kCntStride + ql], 1u);
                             if (emit || want_bm) bwd = backward_tap(cr.p, v, st, tapmap);
-                            if (want_bm && bwd != kNoTap) atomicOr(&bmk[ql], 1u << bwd);
+                            if (want_bm && bwd != kNoTap) atomicOr(&bmk[ql + ((bwd >> 5) << 6)], 1u << (bwd & 31u));
                         }
                     }
                     if (emit) {
@@ -662,7 +663,10 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
         int32_t *tc = tcount + ((size_t)b * ntiles + qt) * st.ntap * kTile;
         for (int e = threadIdx.x; e < st.ntap * kTile; e += blockDim.x) tc[e] = (int32_t)cnt[(e >> 6) * kCntStride + (e & 63)];
     }
-    if (want_bm && threadIdx.x < 64) qbm[((size_t)b * ntiles + qt) * 64 + threadIdx.x] = bmk[threadIdx.x];
+    if (want_bm && threadIdx.x < 64) {
+        qbm[((size_t)b * ntiles + qt) * 64 + threadIdx.x] = bmk[threadIdx.x];
+        if (st.ntap > 32) qbm_hi[((size_t)b * ntiles + qt) * 64 + threadIdx.x] = bmk[64 + threadIdx.x];
+    }
     // commit: the last query tile of the cloud to finish marks the slot's lists as built from the current
     // content.  Every workgroup of the cloud passed the validity check before the ticket can reach its final
     // value, and the marks are only read by later launches, so no fence is needed.
@@ -687,9 +691,9 @@ __global__ __launch_bounds__(256) void search_kernel(const PointRec<T> *__restri
                                                      PairEntry *__restrict__ pairs, CacheCtl cc,
                                                      uint2 *__restrict__ segs, uint2 *__restrict__ qsegs,
                                                      const T *__restrict__ cmin, int32_t *__restrict__ tcount,
-                                                     uint32_t *__restrict__ qbm)
+                                                     uint32_t *__restrict__ qbm, uint32_t *__restrict__ qbm_hi)
 {
-    search_tile<T, WIN>(pts, boxes, st, N, ntiles, gtiles, ngroups, bm, count, pairs, cc, segs, qsegs, cmin, tcount, qbm);
+    search_tile<T, WIN>(pts, boxes, st, N, ntiles, gtiles, ngroups, bm, count, pairs, cc, segs, qsegs, cmin, tcount, qbm, qbm_hi);
 }
 
 // Several stencils over the same sorted points in ONE launch (blockIdx.y = stencil): the models' layers share
@@ -702,7 +706,7 @@ template <typename T> struct SearchJob {
     int32_t *count, *tcount;
     PairEntry *pairs;
     uint2 *segs, *qsegs;
-    uint32_t *qbm;
+    uint32_t *qbm, *qbm_hi;
 };
 template <typename T> struct SearchJobs {
     SearchJob<T> job[kMaxJobs];
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(256) void search_multi_kernel(const PointRec<T> *__
 {
     const SearchJob<T> &j = jobs.job[blockIdx.y];
     search_tile<T, WIN>(pts, boxes, j.st, N, ntiles, gtiles, ngroups, bm, j.count, j.pairs, j.cc, j.segs, j.qsegs, cmin, j.tcount,
-                        j.qbm);
+                        j.qbm, j.qbm_hi);
 }
 
 }  // namespace conv3p

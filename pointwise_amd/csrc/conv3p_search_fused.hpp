@@ -148,7 +148,7 @@ template <typename T> struct FusedJob {
     int32_t *count, *tcount;
     PairEntry *pairs;
     uint2 *segs, *qsegs;
-    uint32_t *qbm;
+    uint32_t *qbm, *qbm_hi;   // backward taps of every centre's list: bit f' & 31 of plane f' >> 5 (qbm_hi: filters of 33 .. 64 taps)
     // lower edge of tap k's one-voxel acceptance interval along axis a, relative to the centre, in base buckets:
     // (k * step - full / 2) * 16  (host, double -> float)
     float clo[3][kFMaxExt];
@@ -170,7 +170,7 @@ __host__ __device__ inline FusedLds fused_lds(int ntap, int maxfull, int elem, i
     L.tapmap = off; off += f_a16((size_t)3 * maxfull * 2);
     L.cnt = off; off += f_a16((size_t)ntap * kCntStride * 4);
     L.cen = off; off += (size_t)64 * 12 * elem;          // per centre: lo[3], hi[3], p[3], 3 words of padding
-    L.bmk = off; off += 64 * 4;
+    L.bmk = off; off += (ntap > 32 ? 128 : 64) * 4;
     L.nqw = off; off += (size_t)kWavesPerBlock * 64 * 4;
     L.misc = off; off += 16;
     L.red = off; off += 6 * 8;
@@ -310,7 +310,7 @@ __device__ __forceinline__ void fused_resolve(const Stencil<T> &st, T rvoxel, co
     }
     if (fwd != kNoTap) {
         atomicAdd(&cnt[fwd * kCntStride + ql], 1u);
-        if (want_bm && bwd != kNoTap) atomicOr(&bmk[ql], 1u << bwd);
+        if (want_bm && bwd != kNoTap) atomicOr(&bmk[ql + ((bwd >> 5) << 6)], 1u << (bwd & 31u));
     }
 }
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
     const PointRec<T> me = cloud_pts[(size_t)qt * kTile + lane];
     const float pf[3] = {(float)me.x, (float)me.y, (float)me.z};
     const bool qvalid = me.idx >= 0 && finite3(pf[0], pf[1], pf[2]);
-    const bool want_bm = job.qbm != nullptr && st.ntap <= 32;
+    const bool want_bm = job.qbm != nullptr && (st.ntap <= 32 || (st.ntap <= 64 && job.qbm_hi != nullptr));
 
     // ---- prologue: tap table, zeroed populations, the centres' exact data, extreme centres per axis
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         }
         cen[lane] = r;
         bmk[lane] = 0;
+        if (st.ntap > 32) bmk[64 + lane] = 0;
     } else {
         const int a = wave - 1;
         const T pa = a == 0 ? me.x : (a == 1 ? me.y : me.z);
@@ -694,7 +695,10 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
             int32_t *tc = job.tcount + ((size_t)b * ntiles + qt) * st.ntap * kTile;
             for (int f = wave; f < st.ntap; f += kWavesPerBlock) tc[f * kTile + lane] = (int32_t)cnt[f * kCntStride + lane];
         }
-        if (want_bm && wave == 0) job.qbm[((size_t)b * ntiles + qt) * 64 + lane] = bmk[lane];
+        if (want_bm && wave == 0) {
+            job.qbm[((size_t)b * ntiles + qt) * 64 + lane] = bmk[lane];
+            if (st.ntap > 32) job.qbm_hi[((size_t)b * ntiles + qt) * 64 + lane] = bmk[64 + lane];
+        }
     }
     // commit: the last query tile of the cloud to finish marks the slot's lists as built from the current content
     __syncthreads();

@@ -615,6 +615,33 @@ def test_results_are_bitwise_reproducible(dev):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("ci,co,filt,s,kind", [(9, 9, (4, 4, 4), (2, 2, 2), "modelnet"), (3, 9, (3, 3, 5), (2, 2, 2), "modelnet"),
+                                               (9, 9, (3, 5, 3), (3, 2, 3), "room"), (9, 3, (4, 4, 4), (3, 3, 3), "lattice")])
+def test_filters_of_33_to_64_taps_keep_the_populated_rows_backward(dev, ci, co, filt, s, kind):
+    """The reference takes any filter extents from the tensor's shape (tf_conv3p_atrous.cpp:425-429).  Filters of 33 .. 64
+    taps run the populated-rows backward with 64-bit tap sets (two planes of `qbm`): even dilated extents through the
+    tile-pair search with the grid's candidate window, odd ones through the fused search.  Oracle parity, reproducible."""
+    B, N = 3, 1500
+    P, X, W, dY = make_case(kind, B, N, ci, co, filt, seed=1840)
+    ntap = filt[0] * filt[1] * filt[2]
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=ntap, max_cin=ci, max_cout=co, sparse_neighbourhoods=True)
+    a = _both(dev, cache, P, X, W, dY, s)
+    b = _both(dev, cache, P, X, W, dY, s)
+    c = _both(dev, None, P, X, W, dY, s)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    ry = oracle.forward(P, X, W, s, VOX)
+    rdx, rdw = oracle.backward(dY, P, X, W, s, VOX)
+    r64 = oracle.backward(dY.astype(np.float64), P.astype(np.float64), X.astype(np.float64), W.astype(np.float64), s, VOX)
+    tol_y, tol_w = TOL[np.dtype(np.float32)]
+    # (the cache carries the short-lists hint, so `a` is the populated-rows kernel's result; the stateless call `c` lets
+    # the lists just built choose between it and the dense-G kernel: a different summation order, the same tolerance)
+    for got in (a, c):
+        assert rel_err(got[0].cpu().numpy(), ry) <= tol_y
+        assert rel_err(got[1].cpu().numpy(), rdx) <= tol_y
+        assert rel_err(got[2].cpu().numpy(), rdw) <= max(tol_w, 4.0 * rel_err(rdw, r64[1]))
+
+
 def test_stack_with_cache_hints_over_changing_batches(dev):
     """What bench.py does: one Conv3pStack (neighbour cache + POINTS_UNCHANGED hints inside a step) fed a
     different batch every step must give exactly what a cache-less stack gives, step after step."""
