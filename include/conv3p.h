@@ -334,6 +334,13 @@ int conv3p_stack_backward_f64(const conv3p_stack_desc *desc, const double *point
                               double *grad_input, double *const *grad_filters, void *scratch, size_t scratch_bytes,
                               void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, void *stream);
 
+/* The stack-level passes run the hidden layers as ONE launch per pass where the stack, the cache and the device allow
+ * it (pointwise_amd/csrc/conv3p_stack_fused.hpp: per-cloud barriers between the layers).  Diagnostics, SYNCHRONISES the
+ * device: how many such launches this cache has seen, and the error bits they left (0 = none; 1: a barrier wait gave up,
+ * 2: the tiles of a cloud did not share an XCC).  The reference has no counterpart (one op = one launch sequence there,
+ * tf_conv3p_atrous.cu:541-642). */
+int conv3p_cache_fused_status(void *cache, unsigned *forward_launches, unsigned *backward_launches, unsigned *error_bits);
+
 /* ---------------------------------------------------------------------------------------------
  * The providers' host pre-step on the device.  The reference prepares every batch with
  * per-cloud numpy loops -- rotate_point_cloud + jitter_point_cloud (/root/reference/modelnet_provider.py:23-75) and

@@ -77,6 +77,7 @@ SYMBOLS = {
     "conv3p_cache_bytes": (_sz, [_i, _i, _i, ctypes.POINTER(CacheConfig)]),
     "conv3p_cache_forget": (_i, [_vp]),
     "conv3p_cache_init": (_i, [_vp, _sz, _vp]),
+    "conv3p_cache_fused_status": (_i, [_vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
     "conv3p_profile_enable": (_i, [_i]),
     "conv3p_profile_reset": (_i, []),
     "conv3p_profile_kinds": (_i, []),

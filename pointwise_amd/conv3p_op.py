@@ -79,6 +79,15 @@ class NeighborCache:
         return (self.key == (int(B), int(N), dtype, torch.device(device)) and ntap <= self.cfg.max_taps
                 and cin <= self.cfg.max_Cin and cout <= self.cfg.max_Cout)
 
+    def fused_status(self):
+        """(forward launches, backward launches, error bits) of the fused stack launches this cache has served
+        (conv3p_cache_fused_status; synchronises the device)."""
+        f, b, e = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_uint(0)
+        rc = _lib.load().conv3p_cache_fused_status(self.buf.data_ptr(), ctypes.byref(f), ctypes.byref(b), ctypes.byref(e))
+        if rc != _lib.OK:
+            raise Conv3pRuntimeError("conv3p_cache_fused_status: status %d" % rc)
+        return f.value, b.value, e.value
+
     def __del__(self):
         try:
             _lib.load().conv3p_cache_forget(self.buf.data_ptr())

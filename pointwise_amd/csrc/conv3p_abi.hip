@@ -15,12 +15,14 @@
 // The stateless entry points run the same kernels on the caller's scratch with force = 1.
 #include "../../include/conv3p.h"
 #include "conv3p_kernels.hpp"
+#include "conv3p_stack_fused.hpp"
 #include "conv3p_prestep.hpp"
 #include "conv3p_head.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -171,6 +173,7 @@ template <typename T> struct Layout {
     T *cmin;   // [B][3] origin of the reference's uniform grid (stencils with an even dilated extent only)
     unsigned long long *ftab;   // [B][ntiles][kFTableU64] per-tile window tables of the fused search (sorted clouds only)
     uint32_t *tab_version, *tab_ticket;   // [B] version of the cloud its tables were built from / tiles done (tile_tables_kernel)
+    uint32_t *tab_inv;                    // [B] bits of the inv16 (= 16 / voxel) the tables were built with
     // per slot
     struct Slot {
         uint32_t *built_version, *cursor, *ticket;
@@ -222,6 +225,7 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
                  : nullptr;
     L.tab_version = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
     L.tab_ticket = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
+    L.tab_inv = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B));
     size_t ppc = (size_t)N * (size_t)pairs_per_point;
     if ((size_t)B * ppc > 0xFFFFFFF0ull) ppc = B ? 0xFFFFFFF0ull / (size_t)B : 0;
     if (ppc > 0x7FFFFFFFull) ppc = 0x7FFFFFFFull;   // headroom for the allocator's transient overshoot (search_tile P2)
@@ -576,7 +580,7 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
     const float inv16 = (float)((double)kFR / (double)c.st.voxel);
     Scope sc(K_SEARCH, c.s);
     hipLaunchKernelGGL(tile_tables_kernel<T>, dim3((d.ntiles + kWavesPerBlock - 1) / kWavesPerBlock, d.B), dim3(256), 0, c.s,
-                       c.L.pts, d.ntiles, inv16, c.L.ftab, c.cc.version, c.L.tab_version, c.L.tab_ticket, c.cc.force);
+                       c.L.pts, d.ntiles, inv16, c.L.ftab, c.cc.version, c.L.tab_version, c.L.tab_ticket, c.L.tab_inv, c.cc.force);
     bool ext3 = true;
     for (int k = 0; k < njobs; ++k)
         for (int a = 0; a < 3; ++a) ext3 &= jobs.job[k].st.ext[a] == 3;
@@ -1341,6 +1345,13 @@ struct CacheHost {
     const void *pending_points = nullptr;
     int pending_layers = 0;
     std::vector<hipEvent_t> ready;
+    // fused stack launches (conv3p_stack_fused.hpp): the per-cloud arrival counters -- a small device allocation of the
+    // library's own (the caller's cache bytes may be garbage; a counter must not be), [kind][clouds][kSyncLineWords] + one
+    // error word -- and the value every counter of a kind holds between launches
+    uint32_t *sync = nullptr;
+    int sync_clouds = 0;
+    uint32_t sync_base[2] = {0u, 0u};
+    uint32_t fused_launches[2] = {0u, 0u};
 };
 std::mutex g_cache_mu;
 std::map<void *, CacheHost> g_caches;
@@ -1401,8 +1412,13 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
         h.ppp != wh.ppp) {
         std::vector<hipEvent_t> keep;
         keep.swap(h.ready);            // the stack-level entry points' events outlive a re-shape of the cache
+        uint32_t *const ksync = h.sync;   // ... and so do the fused launches' counters
+        const int kclouds = h.sync_clouds;
+        const uint32_t kb0 = h.sync_base[0], kb1 = h.sync_base[1], kf0 = h.fused_launches[0], kf1 = h.fused_launches[1];
         h = CacheHost();
         h.ready.swap(keep);
+        h.sync = ksync; h.sync_clouds = kclouds; h.sync_base[0] = kb0; h.sync_base[1] = kb1;
+        h.fused_launches[0] = kf0; h.fused_launches[1] = kf1;
         h.B = d.B; h.N = d.N; h.elem = (int)sizeof(T); h.ntap_max = ntap_max; h.nslots = wh.nslots; h.ppp = wh.ppp;
         h.tags.assign(wh.nslots, 0ull);
         h.stamp.assign(wh.nslots, 0ull);
@@ -1992,6 +2008,195 @@ int stack_geometry(const conv3p_stack_desc *sd, const T *points, T voxel, int B,
     return CONV3P_OK;
 }
 
+
+// ----------------------------------------------------------------------------- fused stack launches (conv3p_stack_fused.hpp)
+// Per device, once: the placement census (is workgroup b of a 2048-workgroup grid on the same XCC for every b of one
+// residue mod 8?) and the CU count.  One host synchronisation, at the first stack call of the process.
+struct FusedDevice {
+    bool ok = false;
+    uint32_t xcc_of[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cus = 0;
+};
+const FusedDevice &fused_device()
+{
+    static std::mutex mu;
+    static std::map<int, FusedDevice> devs;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = devs.find(dev);
+    if (it != devs.end()) return it->second;
+    FusedDevice fd;
+    const char *off = std::getenv("CONV3P_NO_FUSED_STACK");   // developer A/B: the per-layer launches
+    hipDeviceProp_t prop;
+    if ((off == nullptr || off[0] == '0') && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        fd.cus = prop.multiProcessorCount;
+        constexpr int kCensus = 2048;
+        uint32_t *d = nullptr;
+        std::vector<uint32_t> h(kCensus, 0xFFFFFFFFu);
+        if (hipMalloc(&d, sizeof(uint32_t) * kCensus) == hipSuccess) {
+            hipLaunchKernelGGL(xcc_census_kernel, dim3(kCensus), dim3(256), 0, nullptr, d);
+            if (hipMemcpy(h.data(), d, sizeof(uint32_t) * kCensus, hipMemcpyDeviceToHost) == hipSuccess) {
+                fd.ok = true;
+                for (int i = 0; i < 8; ++i) fd.xcc_of[i] = h[i];
+                for (int b = 0; b < kCensus; ++b) fd.ok &= h[b] == fd.xcc_of[b & 7];
+            }
+            (void)hipFree(d);
+        }
+        (void)hipGetLastError();
+    }
+    return devs.emplace(dev, fd).first->second;
+}
+// workgroups of `kern` (256 threads, `lds` bytes of dynamic LDS) the device holds at once
+int fused_capacity(const void *kern, size_t lds, int cus)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, size_t>, int> memo;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(kern, lds);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second * cus;
+    int nb = 0;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds) != hipSuccess)
+        nb = 0;
+    (void)hipGetLastError();
+    memo[key] = nb;
+    return nb * cus;
+}
+// the cache's arrival counters (created at the first fused launch on it; zero-filled once, never reset: the host tracks
+// their value)
+uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &base, uint32_t *&err)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CacheHost &h = g_caches[cache];
+    if (h.sync != nullptr && h.sync_clouds < B) {
+        (void)hipFree(h.sync);   // (synchronises: nothing can still be using it)
+        h.sync = nullptr;
+    }
+    if (h.sync == nullptr) {
+        const size_t words = (size_t)2 * B * kSyncLineWords + kSyncLineWords;
+        if (hipMalloc(&h.sync, words * sizeof(uint32_t)) != hipSuccess || hipMemset(h.sync, 0, words * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            h.sync = nullptr;
+            return nullptr;
+        }
+        h.sync_clouds = B;
+        h.sync_base[0] = h.sync_base[1] = 0u;
+    }
+    base = h.sync_base[kind];
+    h.sync_base[kind] += arrivals;
+    h.fused_launches[kind] += 1u;
+    err = h.sync + (size_t)2 * h.sync_clouds * kSyncLineWords;
+    return h.sync + (size_t)kind * h.sync_clouds * kSyncLineWords;
+}
+
+template <typename T> size_t forward_lds_bytes(const Stencil<T> &st, int ci, int co)
+{
+    return lds_common(st) + a16((size_t)st.ntap * fwd_wstr<T>(ci, co) * sizeof(T)) + a16((size_t)st.ntap * kCntStride * sizeof(T)) + 256 +
+           a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * co * 64 * sizeof(T));
+}
+
+// Can the hidden layers of this stack run as fused launches on this cache?  Decided from the description alone, BEFORE any
+// call touches the cache's host record.  (fp32; in_channels 3 or 9 -> 9 -> 9 ...; odd dilated extents; one search group;
+// enough slots for the strides not to evict each other; the whole grid resident at once; census passed.)
+template <typename T>
+bool stack_fusable(const conv3p_stack_desc *sd, T voxel, int B, int N, const conv3p_cache_config *cfg, size_t scratch_cap_needed,
+                   size_t scratch_cap)
+{
+    if constexpr (sizeof(T) != 4) {
+        return false;
+    } else {
+        if (sd->hidden != 9 || (sd->in_channels != 3 && sd->in_channels != 9) || sd->n_hidden < 2 || sd->n_hidden > kStackMaxFused) return false;
+        if (sd->fz * sd->fy * sd->fx > 32 || N <= kTile || N > kFusedMaxPoints) return false;
+        if (scratch_cap_needed > scratch_cap) return false;
+        int distinct = 0;
+        for (int l = 0; l < stack_layers(sd); ++l) {
+            bool dup = false;
+            for (int m = 0; m < l; ++m) dup |= sd->strides[m][0] == sd->strides[l][0] && sd->strides[m][1] == sd->strides[l][1] && sd->strides[m][2] == sd->strides[l][2];
+            distinct += dup ? 0 : 1;
+        }
+        if (cfg->slots < distinct) return false;
+        const int ntiles = (N + kTile - 1) / kTile;
+        if (carve<T>(B, N, ntiles, cfg->max_taps, 1, cfg->pairs_per_point > 0 ? cfg->pairs_per_point : kDefaultPairsPerPoint, 0, nullptr).ngroups != 1) return false;
+        for (int l = 0; l < sd->n_hidden; ++l) {
+            Dims d{B, N, 9, 9, sd->fz, sd->fy, sd->fx, sd->fz * sd->fy * sd->fx, ntiles};
+            if (check(d, sd->strides[l], (double)voxel, true) != CONV3P_OK) return false;
+            if (make_stencil<T>(d, sd->strides[l], voxel).window) return false;
+        }
+        return fused_device().ok;
+    }
+}
+
+// forward of the hidden layers in ONE launch.  CONV3P_ERR_UNSUPPORTED (nothing enqueued, nothing recorded): take the per-layer path.
+template <typename T>
+int stack_forward_fused(const conv3p_stack_desc *sd, const T *points, const T *input, const T *const *filters, T voxel, int B, int N,
+                        T *concat, void *cache, size_t cache_bytes, const conv3p_cache_config *cfg, hipStream_t s, bool geometry_enqueued)
+{
+    if constexpr (sizeof(T) != 4) {
+        return CONV3P_ERR_UNSUPPORTED;
+    } else {
+        const int nh = sd->n_hidden, H = sd->hidden, CW = nh * H;
+        const size_t rows = (size_t)B * N;
+        const size_t handoff = up(rows * H * sizeof(T));
+        const Where wh0 = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
+                                     cfg->max_Cin, cfg->max_Cout, 0);
+        if (!stack_fusable<T>(sd, voxel, B, N, cfg, handoff * (size_t)(nh - 1), wh0.scratch_cap)) return CONV3P_ERR_UNSUPPORTED;
+        const FusedDevice &fd = fused_device();
+        const int ntiles = (N + kTile - 1) / kTile;
+        Dims d0{B, N, sd->in_channels, H, sd->fz, sd->fy, sd->fx, sd->fz * sd->fy * sd->fx, ntiles};
+        const BlockMap bm = make_blockmap(d0);
+        size_t lds = 0;
+        for (int l = 0; l < nh; ++l) {
+            Dims d = d0;
+            d.Cin = l == 0 ? sd->in_channels : H;
+            lds = std::max(lds, forward_lds_bytes<T>(make_stencil<T>(d, sd->strides[l], voxel), d.Cin, H));
+        }
+        const void *kern = sd->in_channels == 3 ? reinterpret_cast<const void *>(stack_forward_kernel<T, 3, 9>)
+                                                : reinterpret_cast<const void *>(stack_forward_kernel<T, 9, 9>);
+        if (lds > kMaxLds || (int)grid_of(bm) > fused_capacity(kern, lds, fd.cus)) return CONV3P_ERR_UNSUPPORTED;
+        for (int l = 0; l < nh; ++l)
+            if (!filters[l]) return CONV3P_ERR_INVALID_ARGUMENT;
+        // from here on the cache's host record is touched exactly as the per-layer calls would touch it
+        StackFwdArgs<T> a{};
+        for (int l = 0; l < nh; ++l) {
+            const int flags = ((l > 0 || geometry_enqueued) ? CONV3P_CACHE_POINTS_UNCHANGED : 0) |
+                              (cfg->flags & (CONV3P_CACHE_SPARSE_NEIGHBOURHOODS | CONV3P_CACHE_DENSE_NEIGHBOURHOODS));
+            const Where wh = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
+                                        cfg->max_Cin, cfg->max_Cout, flags);
+            Dims d = d0;
+            d.Cin = l == 0 ? sd->in_channels : H;
+            Call<T> c;
+            TRY(begin_call<T>(c, d, sd->strides[l], voxel, handoff * (size_t)(nh - 1), wh, s));
+            TRY(run_prep<T>(points, c));
+            TRY(run_cloud_min<T>(points, c));
+            TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
+            const auto &S = c.L.slot[c.slot];
+            StackFwdLayer<T> &L = a.layer[l];
+            L.st = c.st;
+            L.count = S.count; L.tcount = S.tcount; L.pairs = S.pairs; L.segs = S.segs; L.qsegs = S.qsegs;
+            char *hand = reinterpret_cast<char *>(c.L.partials);
+            // layer l gathers the dense hand-off copy of layer l - 1's activation (a buffer of its own: no stale L1 line)
+            L.input = l == 0 ? input : reinterpret_cast<const T *>(hand + handoff * (size_t)(l - 1));
+            L.filter = filters[l];
+            L.output = concat + (size_t)H * l;
+            L.out2 = l + 1 < nh ? reinterpret_cast<T *>(hand + handoff * (size_t)l) : nullptr;
+            L.ld_out2 = H;
+            L.ld = RowLd{l == 0 ? sd->in_channels : H, CW, H, d.Cin, d.Cin};
+            if (l == 0) {
+                a.pts = c.L.pts; a.boxes = c.L.boxes; a.cmin = nullptr;
+            }
+        }
+        a.N = N; a.ntiles = ntiles; a.nl = nh; a.bm = bm;
+        a.sync = fused_sync(cache, B, 0, (uint32_t)(ntiles * (nh - 1)), a.base, a.err);
+        if (a.sync == nullptr) return CONV3P_ERR_LAUNCH;
+        Scope sc(K_FORWARD, s);
+        if (sd->in_channels == 3) hipLaunchKernelGGL((stack_forward_kernel<T, 3, 9>), dim3(grid_of(bm)), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((stack_forward_kernel<T, 9, 9>), dim3(grid_of(bm)), dim3(256), lds, s, a);
+        return hip_ok();
+    }
+}
+
 template <typename T>
 int stack_prefetch_impl(const conv3p_stack_desc *sd, const T *points, T voxel, int B, int N, void *cache,
                         size_t cache_bytes, const conv3p_cache_config *cfg, void *stream, void *after_stream)
@@ -2038,7 +2243,19 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
     // prefetched geometry (normally finished long ago, under the previous batch's backward): ONE wait on the last
     // layer's event covers them all; geometry enqueued just now: per-layer waits, so that layer 0 starts early
     if (prefetched && hipStreamWaitEvent(main, ev[nl - 1], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
-    for (int l = 0; l < nl; ++l) {
+    // the hidden layers as ONE launch (conv3p_stack_fused.hpp) where the stack, the cache and the device allow it
+    int first = 0;
+    {
+        const Where wh0 = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
+                                     cfg->max_Cin, cfg->max_Cout, 0);
+        if (stack_fusable<T>(sd, voxel, B, N, cfg, up((size_t)B * N * sd->hidden * sizeof(T)) * (size_t)(sd->n_hidden - 1), wh0.scratch_cap)) {
+            if (events && !prefetched && hipStreamWaitEvent(main, ev[sd->n_hidden - 1], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
+            const int rc = stack_forward_fused<T>(sd, points, input, filters, voxel, B, N, concat, cache, cache_bytes, cfg, main, events);
+            if (rc == CONV3P_OK) first = sd->n_hidden;
+            else if (rc != CONV3P_ERR_UNSUPPORTED) return rc;
+        }
+    }
+    for (int l = first; l < nl; ++l) {
         if (events && !prefetched && hipStreamWaitEvent(main, ev[l], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
         conv3p_cache_config c2 = *cfg;
         c2.flags = ((l > 0 || events) ? CONV3P_CACHE_POINTS_UNCHANGED : 0) |   // the first call of a step re-validates
@@ -2075,7 +2292,85 @@ template <typename T> size_t stack_scratch_bytes(const conv3p_stack_desc *sd, in
     // two ping-pong gradient buffers + the head's gradient w.r.t. the concat + every layer's grad_filter partials
     size_t b = up(rows * wide * sizeof(T)) * 2 + up(rows * (size_t)sd->n_hidden * sd->hidden * sizeof(T));
     for (int l = 0; l < stack_layers(sd); ++l) b += stack_region_bytes<T>(sd, l, B, N);
+    // + the fused launch's gradient hand-off buffers, one per hidden layer (conv3p_stack_fused.hpp: every layer's rows in a
+    // buffer of their own)
+    b += up(rows * (size_t)sd->hidden * sizeof(T)) * (size_t)sd->n_hidden;
     return b;
+}
+
+
+// backward of the hidden layers nh-1 .. 1 in ONE launch (populated-rows kernel; needs the caller's SPARSE hint: the fused
+// launch cannot pick the kernel per layer on the device).  G[l] = gradient w.r.t. the conv output of hidden layer l, dense
+// [B][N][H], each in a buffer of its own.  CONV3P_ERR_UNSUPPORTED (nothing enqueued): take the per-layer path.
+template <typename T>
+int stack_backward_fused(const conv3p_stack_desc *sd, const T *points, const T *const *filters, T voxel, int B, int N, const T *concat,
+                         const T *ext, int ld_ext, T *const *G, DeferredReduce<T> *red, T *const *grad_filters, void *cache, size_t cache_bytes,
+                         const conv3p_cache_config *cfg, hipStream_t s)
+{
+    if constexpr (sizeof(T) != 4) {
+        return CONV3P_ERR_UNSUPPORTED;
+    } else {
+        const int nh = sd->n_hidden, H = sd->hidden, CW = nh * H;
+        if ((cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS) == 0) return CONV3P_ERR_UNSUPPORTED;
+        const Where wh0 = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
+                                     cfg->max_Cin, cfg->max_Cout, 0);
+        if (!stack_fusable<T>(sd, voxel, B, N, cfg, 0, wh0.scratch_cap)) return CONV3P_ERR_UNSUPPORTED;
+        const FusedDevice &fd = fused_device();
+        const int ntiles = (N + kTile - 1) / kTile;
+        Dims d{B, N, H, H, sd->fz, sd->fy, sd->fx, sd->fz * sd->fy * sd->fx, ntiles};
+        const BlockMap bm = make_blockmap(d);
+        size_t lds = 0;
+        int caps[kStackMaxFused];
+        for (int l = nh - 1; l >= 1; --l) {
+            size_t sl = 0;
+            caps[l] = sparse_cap<T>(make_stencil<T>(d, sd->strides[l], voxel), H, H, sl);
+            if (caps[l] <= 0 || sl > 40960) return CONV3P_ERR_UNSUPPORTED;   // (undilated layers: dense G; four workgroups per CU)
+            lds = std::max(lds, sl);
+        }
+        const void *kern = reinterpret_cast<const void *>(stack_backward_kernel<T, 9>);
+        if ((int)grid_of(bm) > fused_capacity(kern, lds, fd.cus)) return CONV3P_ERR_UNSUPPORTED;
+        StackBwdArgs<T> a{};
+        int k = 0;
+        for (int l = nh - 1; l >= 1; --l, ++k) {
+            const Where wh = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
+                                        cfg->max_Cin, cfg->max_Cout,
+                                        CONV3P_CACHE_POINTS_UNCHANGED | (cfg->flags & (CONV3P_CACHE_SPARSE_NEIGHBOURHOODS | CONV3P_CACHE_DENSE_NEIGHBOURHOODS)));
+            Call<T> c;
+            TRY(begin_call<T>(c, d, sd->strides[l], voxel, backward_scratch_bytes(d, (int)sizeof(T), wh.ppp), wh, s));
+            TRY(run_prep<T>(points, c));
+            TRY(run_cloud_min<T>(points, c));
+            TRY(run_search<T>(c, c.L.slot[c.slot].count, true));
+            const auto &S = c.L.slot[c.slot];
+            StackBwdLayer<T> &L = a.layer[k];
+            L.st = c.st;
+            L.count = S.count; L.pairs = S.pairs; L.segs = S.segs; L.qsegs = S.qsegs; L.qbm = S.qbm;
+            L.grad_out = G[l];
+            L.input = concat + (size_t)H * (l - 1);
+            L.filter = filters[l];
+            L.addend = ext + (size_t)H * (l - 1);
+            L.grad_input = G[l - 1];
+            L.partials = red[l].region;
+            L.ld = RowLd{CW, H, H, H, ld_ext};
+            L.cap = caps[l];
+            red[l].job = ReduceJob<T>{red[l].region, grad_filters[l], (int)grid_of(bm), (unsigned)((size_t)d.ntap * H * H)};
+            if (k == 0) {
+                a.pts = c.L.pts; a.boxes = c.L.boxes; a.cmin = nullptr;
+            }
+        }
+        a.N = N; a.ntiles = ntiles; a.nl = k; a.bm = bm;
+        a.nw = (size_t)d.ntap * H * H;
+        a.top_act = concat + (size_t)H * (nh - 1);
+        a.top_ext = ext + (size_t)H * (nh - 1);
+        a.top_g = G[nh - 1];
+        a.ld_act = CW;
+        a.ld_ext = ld_ext;
+        a.sync = fused_sync(cache, B, 1, (uint32_t)(ntiles * k), a.base, a.err);
+        if (a.sync == nullptr) return CONV3P_ERR_LAUNCH;
+        Scope sc(K_BACKWARD, s);
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((stack_backward_kernel<T, 9>), dim3(grid_of(bm)), dim3(256), lds, s, a);
+        return hip_ok();
+    }
 }
 
 template <typename T>
@@ -2141,6 +2436,21 @@ int stack_backward_impl(const conv3p_stack_desc *sd, const T *points, const T *i
                              &red[nh]));
         ext = dconcat;
     }
+    // the hidden layers nh-1 .. 1 as ONE launch (conv3p_stack_fused.hpp) where the stack, the cache and the device allow it
+    {
+        T *G[CONV3P_STACK_MAX_LAYERS];
+        char *gp = sp + 2 * up(rows * wide * sizeof(T)) + up(rows * (size_t)CW * sizeof(T));
+        for (int l = 0; l < stack_layers(sd); ++l) gp += stack_region_bytes<T>(sd, l, B, N);
+        for (int l = 0; l < nh; ++l) G[l] = reinterpret_cast<T *>(gp + up(rows * (size_t)H * sizeof(T)) * (size_t)l);
+        const int rc = stack_backward_fused<T>(sd, points, filters, voxel, B, N, concat, ext, ld_ext, G, red, grad_filters, cache, cache_bytes,
+                                               cfg, static_cast<hipStream_t>(stream));
+        if (rc == CONV3P_OK) {
+            TRY(backward_impl<T>(G[0], points, input, filters[0], sd->strides[0], voxel, B, N, sd->in_channels, H, sd->fz, sd->fy,
+                                 sd->fx, grad_input, grad_filters[0], where(), stream, false, nullptr, nullptr, &red[0]));
+            return reduce_all();
+        }
+        if (rc != CONV3P_ERR_UNSUPPORTED) return rc;
+    }
     // g_l = dL/d(conv output of hidden layer l).  Last hidden layer: only the external gradient reaches its activation.
     T *g = has_head ? gb : ga, *gn = has_head ? ga : gb;
     {
@@ -2199,7 +2509,30 @@ int conv3p_cache_forget(void *cache)
     auto it = g_caches.find(cache);
     if (it != g_caches.end()) {
         for (hipEvent_t e : it->second.ready) (void)hipEventDestroy(e);
+        if (it->second.sync != nullptr) (void)hipFree(it->second.sync);
         g_caches.erase(it);
+    }
+    return CONV3P_OK;
+}
+
+int conv3p_cache_fused_status(void *cache, unsigned *forward_launches, unsigned *backward_launches, unsigned *error_bits)
+{
+    uint32_t *sync = nullptr;
+    int clouds = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_caches.find(cache);
+        if (forward_launches) *forward_launches = it != g_caches.end() ? it->second.fused_launches[0] : 0u;
+        if (backward_launches) *backward_launches = it != g_caches.end() ? it->second.fused_launches[1] : 0u;
+        if (it != g_caches.end()) { sync = it->second.sync; clouds = it->second.sync_clouds; }
+    }
+    if (error_bits) {
+        *error_bits = 0u;
+        if (sync != nullptr &&
+            hipMemcpy(error_bits, sync + (size_t)2 * clouds * kSyncLineWords, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            return CONV3P_ERR_LAUNCH;
+        }
     }
     return CONV3P_OK;
 }

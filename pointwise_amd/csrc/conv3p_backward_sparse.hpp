@@ -64,21 +64,19 @@ template <typename T> __host__ __device__ inline size_t sparse_min_rows(int cin,
     return ((size_t)kWavesPerBlock * cin * 64 + cout - 1) / cout;
 }
 
-template <typename T, int CIN, int COUT, bool BIG = false>   // BIG: filters of 33 .. 64 taps (64-bit tap sets; narrow layers only)
-// (four waves per SIMD -- four workgroups per CU -- for the models' 3- and 9-input layers; 6 and 12 inputs, SceneNN's first
-// layer, which only gets here when dilated, would spill 2 / 16 registers under that cap; so would the 64-bit tap sets of BIG)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (CIN == 3 || CIN == 9)) ? 4 : 2))) void backward_sparse_kernel(
+// The pass of ONE query tile; the whole workgroup calls it.  live: the workgroup has a tile (else it only zeroes its
+// grad_filter partial); slot_idx: index of the workgroup's partial; sync: the hand-off points of a fused stack launch
+// (conv3p_stack_fused.hpp) or NoSync.
+template <typename T, int CIN, int COUT, bool BIG, class Sync>   // BIG: filters of 33 .. 64 taps (64-bit tap sets; narrow layers only)
+__device__ __forceinline__ void backward_sparse_tile(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
     const uint32_t *__restrict__ qbm, const uint32_t *__restrict__ qbm_hi, const T *__restrict__ grad_out, const T *__restrict__ input,
-    const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, BlockMap bm, T *__restrict__ grad_input,
+    const T *__restrict__ filter, const Stencil<T> &st, int N, int ntiles, int ngroups, T *__restrict__ grad_input,
     T *__restrict__ partials, int act, const T *__restrict__ addend, const T *__restrict__ cmin, RowLd ld,
     int cap,   // G rows (slots) the LDS allocation holds; >= 64, so every tap fits a round of its own
-    const uint32_t *__restrict__ sched,   // launch order of the tiles (tile_sched_kernel) or nullptr
-    const uint32_t *__restrict__ regime)  // non-null: run only if the slot's lists are SHORT (*regime == 1, tile_sched_kernel);
-                                          // the host then launches backward_kernel too, which runs in the other case
+    bool live, int b, int qt, unsigned slot_idx, const Sync &sync)
 {
-    if (regime != nullptr && *regime != 1u) return;   // (uniform)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
@@ -129,8 +127,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (C
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
 
-    int b, qt;
-    const bool live = block_to_tile(bm, sched, ntiles, b, qt);   // uniform for the workgroup
     const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
     PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
     if (!live) me.idx = -1;
@@ -206,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (C
     build_rows(mybm);
     __syncthreads();
     if (!live) {   // (uniform) a workgroup past the last cloud: its grad_filter partial is summed like the others
-        T *z = partials + (size_t)blockIdx.x * nw;
+        T *z = partials + (size_t)slot_idx * nw;
         for (uint32_t e = threadIdx.x; e < (uint32_t)nw; e += blockDim.x) z[e] = (T)0;
         return;
     }
@@ -491,7 +487,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (C
         }
     };
     auto phase_B = [&](int t0, int t1, bool accumulate = false) {
-        T *slot_out = partials + (size_t)blockIdx.x * nw;
+        T *slot_out = partials + (size_t)slot_idx * nw;
         // ---- phase B: dW[f'][k][c] = sum over the tap's slots of X[j(slot)][k] * G[slot][c].  fp32: on the matrix cores
         // (v_mfma_f32_16x16x4_f32, an exact fmaf chain: deterministic), wave w takes the round's taps f' == w (mod 4);
         // K = the tap's slots, four per step: A[i][kk] = X[j][i], B[kk][n] = G[slot][n], D[k][c] in registers over the tap.
@@ -713,6 +709,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (C
     T dx[CIN];
     bool red_written = false;   // (uniform)
     SDBG()
+    sync.wait();   // (fused stack launch: phase A gathers other tiles' grad rows of the layer above; every path below has a
+                   // workgroup barrier between here and its first gather)
     if (nrounds == 1) {
         // the common case (every tile of the models' strides >= 2): nothing but phase A's own state is live across it
         zero_G(st.ntap);
@@ -862,6 +860,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (C
         printf("bsp<%d,%d> wg %d wave %d: prologue %lld  zero+sync %lld  phaseA %lld  sync %lld  B %lld  C %lld  reduce+store %lld\n", CIN, COUT,
                (int)blockIdx.x, wave, st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], st_[7] - st_[6]);
 #endif
+    sync.arrive();
+}
+
+template <typename T, int CIN, int COUT, bool BIG = false>
+// (four waves per SIMD -- four workgroups per CU -- for the models' 3- and 9-input layers; 6 and 12 inputs, SceneNN's first
+// layer, which only gets here when dilated, would spill 2 / 16 registers under that cap; so would the 64-bit tap sets of BIG)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (CIN == 3 || CIN == 9)) ? 4 : 2))) void backward_sparse_kernel(
+    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
+    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
+    const uint32_t *__restrict__ qbm, const uint32_t *__restrict__ qbm_hi, const T *__restrict__ grad_out, const T *__restrict__ input,
+    const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups, BlockMap bm, T *__restrict__ grad_input,
+    T *__restrict__ partials, int act, const T *__restrict__ addend, const T *__restrict__ cmin, RowLd ld, int cap,
+    const uint32_t *__restrict__ sched,   // launch order of the tiles (tile_sched_kernel) or nullptr
+    const uint32_t *__restrict__ regime)  // non-null: run only if the slot's lists are SHORT (*regime == 1, tile_sched_kernel);
+                                          // the host then launches backward_kernel too, which runs in the other case
+{
+    if (regime != nullptr && *regime != 1u) return;   // (uniform)
+    int b, qt;
+    const bool live = block_to_tile(bm, sched, ntiles, b, qt);   // uniform for the workgroup
+    backward_sparse_tile<T, CIN, COUT, BIG>(pts, boxes, count, pairs, segs, qsegs, qbm, qbm_hi, grad_out, input, filter, st, N, ntiles, ngroups,
+                                            grad_input, partials, act, addend, cmin, ld, cap, live, b, qt, blockIdx.x, NoSync{});
 }
 
 }  // namespace conv3p

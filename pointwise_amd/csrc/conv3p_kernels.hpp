@@ -859,20 +859,26 @@ __device__ __forceinline__ f32x2 lds_read_b64(const float *p) { return *(lds_cv_
 // global atomics into the zeroed output.
 // A segment marked kSegOverflow makes the workgroup search its query tile itself.
 // ---------------------------------------------------------------------------------
-template <typename T, int CIN, int COUT>
-// Cin <= 12: 4 waves per SIMD = 4 workgroups per CU, so that the 128 workgroups an XCD gets for cfg2 are resident
-// in one round (the unconstrained allocation is 132 VGPRs).  Wider inputs keep their row in registers and would
-// spill under that cap (36 -> 13: 50 spilled VGPRs, 4.6x slower).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && CIN > 0 && CIN <= 12 ? 4 : 1))) void forward_kernel(
+// What a tile's pass does at the hand-off points between the layers of a fused stack launch (conv3p_stack_fused.hpp):
+// nothing, when the layer is a launch of its own.
+struct NoSync {
+    static constexpr bool kActive = false;
+    __device__ __forceinline__ void wait() const {}     // before the first load of another tile's activations
+    __device__ __forceinline__ void arrive() const {}   // after the tile's own rows are stored
+};
 
+// The pass of ONE query tile (b, qt); the whole workgroup calls it.  out2 (or nullptr): a second, dense copy of the tile's
+// output rows [B][N][ld_out2] (the fused stack's hand-off buffer, see conv3p_stack_fused.hpp).
+template <typename T, int CIN, int COUT, class Sync>
+__device__ __forceinline__ void forward_tile(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
-    const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
-    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged,
+    const T *__restrict__ input, const T *__restrict__ filter, const Stencil<T> &st, int N, int ntiles, int ngroups,
+    int cin_rt, int cout_rt, T *__restrict__ output,
     int act,   // act != 0 (small path only): store selu(out), the models' layer (pointcnn2_acsd.py:48-49)
     const T *__restrict__ cmin,   // per-cloud grid origin (window-mode stencils, overflow path only)
     const int32_t *__restrict__ tcount,   // populations tile-major [tile][tap][centre lane] (search_tile)
-    RowLd ld, const uint32_t *__restrict__ sched)   // sched: launch order of the tiles (tile_sched_kernel) or nullptr
+    RowLd ld, int b, int qt, T *__restrict__ out2, int ld_out2, const Sync &sync)
 {
     constexpr bool kSmall = CIN > 0;
     const int cin = kSmall ? CIN : cin_rt;
@@ -901,9 +907,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
     uint32_t sub = lane & 3u, nsub = 4u;   //   ... its index among the centre's lanes, and their number
     uint32_t *share = reinterpret_cast<uint32_t *>(soa);   // the wave's lane-sharing scratch (soa is the overflow path's)
 
-    int b, qt;
-    if (!block_to_tile(bm, sched, ntiles, b, qt)) return;   // uniform
-    if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
 #if CONV3P_ABLATE & 134217728
     long long ft[8];
     int fti = 0, fsteps = 0;
@@ -970,7 +973,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         const bool ok = i < sg.y && code_fwd(rec[sl].code) != kNoTap;
         RowLoader<T, CINR>::load(in_cloud + (size_t)(ok ? ((CONV3P_ABLATE & 1024) ? (rec[sl].cand & 63u) : rec[sl].cand) : 0u) * ld.in, xs[sl]);   // (1024: developer, every gather an L1 hit)
     };
-    auto start_group = [&](int g) {
+    auto start_rows = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + nsub * sl);
+    };
+    auto start_group = [&](int g, bool rows) {
         if (shared) {
             const LaneShare ls = share_lanes(qsegs[tile_id * 64 + wave * 16 + (lane & 15)], share);
             cq = wave * 16 + (int)ls.cl;
@@ -984,13 +991,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
         pe = pairs + sg.x;
 #pragma unroll
         for (int sl = 0; sl < NS - 1; ++sl) rec[sl] = ld_rec(sub + nsub * sl);
-#pragma unroll
-        for (int sl = 0; sl < NS - 2; ++sl) ld_row(sl, sub + nsub * sl);
+        if (rows) start_rows();
     };
-    if (kSmall && !overflow) start_group(0);
+    // (fused stack launch: the neighbour rows are another tile's output of the previous layer -- everything above and the
+    // records are requested first, the rows once the cloud's tiles have all arrived)
+    if (kSmall && !overflow) start_group(0, !Sync::kActive);
+    sync.wait();
     FDBG()
     __syncthreads();
     FDBG()
+    if (Sync::kActive && kSmall && !overflow) start_rows();
     {
         // own populations -> LDS [tap][centre]; the dense small path keeps 1 / (T)count instead (the IEEE quotient,
         // .cpp:483: one division per (centre, tap) here rather than one per pair)
@@ -1060,7 +1070,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 // unconditional from clamped addresses, so hipcc can count the ones in flight.
                 // (NS = 2 for the widest rows, whose three copies would not fit the register file: the row is then
                 // loaded in the step that uses it, as before)
-                if (g > 0) start_group(g);      // (group 0 was started before the barriers)
+                if (g > 0) start_group(g, true);      // (group 0 was started before the barriers)
                 FDBG()
                 FDBG()
                 uint32_t i = sub;
@@ -1159,7 +1169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 T v = (T)0;
                 for (int jj = 0; jj < cnt_l; ++jj) v += src[jj];
                 const int orig = qorig[wave * 16 + ci];
-                if (orig >= 0) out_cloud[(size_t)orig * ld.out + ch] = act ? selu_value(v) : v;
+                if (orig >= 0) {
+                    const T r = act ? selu_value(v) : v;
+                    out_cloud[(size_t)orig * ld.out + ch] = r;
+                    if (out2 != nullptr) out2[((size_t)b * N + orig) * ld_out2 + ch] = r;
+                }
             }
 #if CONV3P_ABLATE & 134217728
             FDBG()
@@ -1177,10 +1191,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 T sum = red[((size_t)0 * COUT + c) * 64 + lane];
 #pragma unroll
                 for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * COUT + c) * 64 + lane];
-                if (me.idx >= 0) out_cloud[(size_t)me.idx * ld.out + c] = act ? selu_value(sum) : sum;
+                if (me.idx >= 0) {
+                    const T r = act ? selu_value(sum) : sum;
+                    out_cloud[(size_t)me.idx * ld.out + c] = r;
+                    if (out2 != nullptr) out2[((size_t)b * N + me.idx) * ld_out2 + c] = r;
+                }
             }
         }
     }
+    sync.arrive();
+}
+
+template <typename T, int CIN, int COUT>
+// Cin <= 12: 4 waves per SIMD = 4 workgroups per CU, so that the 128 workgroups an XCD gets for cfg2 are resident
+// in one round (the unconstrained allocation is 132 VGPRs).  Wider inputs keep their row in registers and would
+// spill under that cap (36 -> 13: 50 spilled VGPRs, 4.6x slower).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && CIN > 0 && CIN <= 12 ? 4 : 1))) void forward_kernel(
+    const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
+    const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
+    const T *__restrict__ input, const T *__restrict__ filter, Stencil<T> st, int N, int ntiles, int ngroups,
+    int cin_rt, int cout_rt, BlockMap bm, T *__restrict__ output, const uint8_t *__restrict__ only_flagged,
+    int act, const T *__restrict__ cmin, const int32_t *__restrict__ tcount,
+    RowLd ld, const uint32_t *__restrict__ sched)   // sched: launch order of the tiles (tile_sched_kernel) or nullptr
+{
+    int b, qt;
+    if (!block_to_tile(bm, sched, ntiles, b, qt)) return;   // uniform
+    if (only_flagged != nullptr && !only_flagged[(size_t)b * ntiles + qt]) return;   // deep path did this tile
+    forward_tile<T, CIN, COUT>(pts, boxes, count, pairs, segs, qsegs, input, filter, st, N, ntiles, ngroups, cin_rt, cout_rt, output,
+                               act, cmin, tcount, ld, b, qt, static_cast<T *>(nullptr), 0, NoSync{});
 }
 
 // ---------------------------------------------------------------------------------

@@ -64,18 +64,21 @@ __global__ __launch_bounds__(256) void tile_tables_kernel(const PointRec<T> *__r
                                                           unsigned long long *__restrict__ tables,
                                                           const uint32_t *__restrict__ version,   // [B] of the clouds' contents (prep)
                                                           uint32_t *__restrict__ tab_version,     // [B] ... the tables were built from
-                                                          uint32_t *__restrict__ tab_ticket, int force)
+                                                          uint32_t *__restrict__ tab_ticket,
+                                                          uint32_t *__restrict__ tab_inv,         // [B] ... and the bits of the inv16 they were built with
+                                                          int force)
 {
     __shared__ __attribute__((aligned(16))) unsigned long long tab[kWavesPerBlock][kFTableU64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * kWavesPerBlock + wave;
     const int b = blockIdx.y;
     if (tile >= ntiles) return;   // (wave-uniform; no workgroup barrier below)
-    // The tables depend on the sorted records alone: a cloud whose content has not changed since they were built keeps
-    // them (round 5: a framework that runs the model op by op launches this kernel eight times per step for one new
-    // batch).  The mark is set by the LAST tile of the cloud to finish -- by then every wave of the cloud has passed
-    // this test -- and read by later launches only.
-    if (!force && tab_version[b] == version[b]) return;
+    // The tables depend on the sorted records and on the voxel size (inv16: bucket index, coarsening shift, window size):
+    // a cloud whose content has not changed since they were built FOR THIS VOXEL keeps them (round 5: a framework that
+    // runs the model op by op launches this kernel eight times per step for one new batch; a cache may hold stencils of
+    // several voxel sizes -- the mark covers both).  It is set by the LAST tile of the cloud to finish -- by then every
+    // wave of the cloud has passed this test -- and read by later launches only.
+    if (!force && tab_version[b] == version[b] && tab_inv[b] == __builtin_bit_cast(uint32_t, inv16)) return;
     const size_t t = (size_t)b * ntiles + tile;
     const PointRec<T> r = pts[t * kTile + lane];
     const float v[3] = {(float)r.x, (float)r.y, (float)r.z};
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(256) void tile_tables_kernel(const PointRec<T> *__r
     if (!force && lane == 0) {
         const uint32_t done = atomicAdd(&tab_ticket[b], 1u);
         if (done + 1u == (uint32_t)ntiles) {
+            tab_inv[b] = __builtin_bit_cast(uint32_t, inv16);
             tab_version[b] = version[b];
             tab_ticket[b] = 0;
         }

@@ -98,6 +98,17 @@ class Conv3pStack:
             for a in range(3):
                 self._desc.strides[li][a] = s
 
+    def fused_status(self):
+        """(forward launches, backward launches, error bits) summed over the stack's caches: how many passes ran as ONE
+        launch (csrc/conv3p_stack_fused.hpp), and whether any of them reported a barrier time-out (1) or a cloud whose
+        tiles did not share an XCC (2).  Synchronises the device."""
+        f = b = e = 0
+        for c in self._caches:
+            if c is not None:
+                cf, cb, ce = c.fused_status()
+                f, b, e = f + cf, b + cb, e | ce
+        return f, b, e
+
     def _ptr_tables(self):
         """Pointer tables of the stack-level C entry points, rebuilt per call: `filters[i]` may have been rebound
         (an optimizer swap, .to())."""

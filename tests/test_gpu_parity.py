@@ -553,6 +553,28 @@ def test_cache_slot_eviction(dev):
             assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5
 
 
+@pytest.mark.parametrize("slots", [1, 3])
+def test_cache_serves_several_voxel_sizes_over_the_same_points(dev, slots):
+    """One cache, unchanged points, stencils of different VOXEL sizes back to back (a new tag, or -- one slot -- an
+    evicted one): the window tables of the fused search are built for one voxel size and must be rebuilt when it
+    changes (the tables' validity mark covered the cloud's content only)."""
+    B, N = 3, 700
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=slots, max_taps=27, max_cin=9, max_cout=9)
+    P, X, W, dY = make_case("modelnet", B, N, 9, 9, seed=815)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tp, tx, tw, tdy = t(P), t(X), t(W), t(dY)
+    for vox, s in ((0.1, (1, 1, 1)), (0.2, (1, 1, 1)), (0.1, (2, 2, 2)), (0.05, (3, 3, 3)), (0.2, (2, 2, 2)), (0.1, (1, 1, 1))):
+        cnt = op.neighbor_count(tp, (3, 3, 3), s, vox).cpu().numpy()
+        y = op.conv3p(tp, tx, tw, s, vox, cache=cache)
+        dx, dw = op.conv3p_grad(tdy, tp, tx, tw, s, vox, cache=cache)
+        assert np.array_equal(cnt, oracle.neighbor_count(P, (3, 3, 3), s, vox))
+        y_s = op.conv3p(tp, tx, tw, s, vox)
+        assert torch.equal(y, y_s), ("cached != stateless", vox, s)
+        assert rel_err(y.cpu().numpy(), oracle.forward(P, X, W, s, vox)) <= 1e-5, (vox, s)
+        dx_ref, dw_ref = oracle.backward(dY, P, X, W, s, vox)
+        assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5, (vox, s)
+
+
 def test_cache_garbage_buffer_is_harmless(dev):
     """A cache whose bytes are garbage (never zero-filled, or recycled) can only cost a rebuild."""
     B, N = 2, 256
