@@ -550,6 +550,9 @@ def main():
     ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
                     help="cfg2 (default; cfg3 at --gpus 8): B=32 x N=2048 per GPU, 4-layer stack.  cfg5: B=16 x N=8192 per "
                          "GPU, one 128->256 layer, one 3.54 MB all-reduce")
+    ap.add_argument("--fused-stack", action="store_true",
+                    help="developer: the hidden layers of a pass as ONE launch (CONV3P_CACHE_FUSED_STACK, opt-in; echoed "
+                         "into config; the default run reports it beside the headline as fused_stack_ms_per_step)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not enqueue the next batch's neighbour search under the current batch's backward")
     args = ap.parse_args()
@@ -593,7 +596,7 @@ def main():
     tP, tX = tPs[0], tXs[0]
     ups = [torch.from_numpy(u).to(dev) for u in ups_np]
     gcat = torch.cat(ups, dim=2).contiguous()      # dL/dconcat (B, N, 36): what the model's dense head hands back
-    st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial)
+    st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial, fused_launch=args.fused_stack)
     counter = [0]
     # set-up, not a step: create the RCCL communicator (seconds on the first collective), allocate the stack's
     # neighbour caches and load the library's code object (one 64-point call) before anything is timed,
@@ -745,12 +748,28 @@ def main():
                "roofline": roofline}
         if os.environ.get("CONV3P_HIP_LIB"):   # developer A/B builds: never silently
             out["config"]["hip_library_override"] = os.environ["CONV3P_HIP_LIB"]
+        if os.environ.get("CONV3P_BENCH_PRESORT"):   # (the input order of the clouds is part of the workload: never silently)
+            out["config"]["developer_presorted_clouds"] = "Morton order (CONV3P_BENCH_PRESORT): NOT the headline workload"
+        if args.fused_stack:
+            out["config"]["fused_stack_launches"] = "CONV3P_CACHE_FUSED_STACK: hidden layers of a pass as one launch (opt-in, --fused-stack)"
+            out["config"]["fused_status"] = list(st.fused_status())
         if world > 1:
             out["rccl_world"] = rccl_world
             out["allreduce_ms_per_step"] = None if allreduce_ms is None else round(allreduce_ms, 4)
             out["allreduce_exposed_ms_per_step"] = None if allreduce_exposed_ms is None else round(allreduce_exposed_ms, 4)
             out["ms_per_step_ranks"] = spread
             out["allreduce_bytes"] = int(st.fused_grad.numel() * 4)
+        if extra and not args.fused_stack:
+            # the same step with the hidden layers of each pass as ONE launch (opt-in CONV3P_CACHE_FUSED_STACK): built in
+            # round 6, measured, not the default
+            st_f = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial, fused_launch=True)
+            st_f.sparse_neighbourhoods = st.sparse_neighbourhoods
+            st_f.prepare(B_PER_GPU, N_POINTS)
+            step_f = make_step(st_f, prefetch)
+            dt_f = timed(dev, step_f, min(args.steps, 30), 5)
+            out["fused_stack_ms_per_step"] = round(dt_f * 1e3, 4)
+            out["fused_stack_status"] = list(st_f.fused_status())
+            del st_f
         if extra:
             # the drop-in boundary as the TF shim drives it: stateless ops, SELU as separate ops
             st_plain = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, use_cache=False)

@@ -152,6 +152,15 @@ typedef struct conv3p_cache_config {
  * (another stencil's wide layer, a narrow layer) simply rebuilds them.  Needs a cache sized for a wide layer
  * (max_Cin / max_Cout of conv3p_cache_config); CONV3P_ERR_WORKSPACE otherwise.  A performance hint only. */
 #define CONV3P_CACHE_PREPARE_DEEP_ORDERS 4
+/* conv3p_stack_forward_* / conv3p_stack_backward_* only, OPT-IN: run the hidden layers of a pass as ONE launch with
+ * per-cloud barriers between the layers (pointwise_amd/csrc/conv3p_stack_fused.hpp) where the stack, the cache and the
+ * device allow it (fp32, in_channels 3 or 9, hidden 9, the whole grid resident at once; the backward also needs
+ * CONV3P_CACHE_SPARSE_NEIGHBOURHOODS).  Same bits for the activations and grad_input as the per-layer launches; grad_filter
+ * sums its partials in another order (tolerance of the op).  Measured (profiles/r06_ab_fused.txt, r06_cfg4_ab.txt): cfg2
+ * 0.420 against 0.436 ms with nothing else on the GPU, 0.420 against 0.417 beside the next batch's search (the fused kernels
+ * hold every slot of the chip while their tiles wait for the slowest tile of their cloud); the rooms of cfg4, whose tiles
+ * differ far more, 1.36 against 1.26 ms.  Hence not the default. */
+#define CONV3P_CACHE_FUSED_STACK 16
 
 size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_config *cfg);
 /* Drop the host-side bookkeeping of a cache buffer (call before freeing it). */

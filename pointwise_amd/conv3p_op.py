@@ -52,8 +52,9 @@ class NeighborCache:
     is decided on the device by content hash, so reusing it with different clouds is always safe."""
 
     def __init__(self, B, N, dtype, device, slots=5, max_taps=27, pairs_per_point=0, max_cin=36, max_cout=41,
-                 sparse_neighbourhoods=None):
+                 sparse_neighbourhoods=None, fused_stack=False):
         lib = _lib.load()
+        self.fused_stack = fused_stack   # CONV3P_CACHE_FUSED_STACK for the stack-level entry points (opt-in)
         self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout, 0)
         # None: the library decides on the device which backward kernel serves the dilated narrow layers; True / False:
         # CONV3P_CACHE_SPARSE_NEIGHBOURHOODS / CONV3P_CACHE_DENSE_NEIGHBOURHOODS (include/conv3p.h), saving an empty launch
@@ -72,7 +73,8 @@ class NeighborCache:
         self.cfg.flags = (_lib.CACHE_POINTS_UNCHANGED if points_unchanged else 0) | \
                          (0 if self.sparse_neighbourhoods is None else _lib.CACHE_SPARSE_NEIGHBOURHOODS
                           if self.sparse_neighbourhoods else _lib.CACHE_DENSE_NEIGHBOURHOODS) | \
-                         (_lib.CACHE_PREPARE_DEEP_ORDERS if deep_orders else 0)
+                         (_lib.CACHE_PREPARE_DEEP_ORDERS if deep_orders else 0) | \
+                         (_lib.CACHE_FUSED_STACK if self.fused_stack else 0)
         return ctypes.addressof(self.cfg)
 
     def fits(self, B, N, dtype, device, ntap, cin, cout):

@@ -1346,8 +1346,8 @@ struct CacheHost {
     int pending_layers = 0;
     std::vector<hipEvent_t> ready;
     // fused stack launches (conv3p_stack_fused.hpp): the per-cloud arrival counters -- a small device allocation of the
-    // library's own (the caller's cache bytes may be garbage; a counter must not be), [kind][clouds][kSyncLineWords] + one
-    // error word -- and the value every counter of a kind holds between launches
+    // library's own (the caller's cache bytes may be garbage; a counter must not be), [kind][clouds][kSyncLineWords]: a
+    // cloud's line = {counter, placement word, error bits} -- and the value every counter of a kind holds between launches
     uint32_t *sync = nullptr;
     int sync_clouds = 0;
     uint32_t sync_base[2] = {0u, 0u};
@@ -2027,9 +2027,8 @@ const FusedDevice &fused_device()
     auto it = devs.find(dev);
     if (it != devs.end()) return it->second;
     FusedDevice fd;
-    const char *off = std::getenv("CONV3P_NO_FUSED_STACK");   // developer A/B: the per-layer launches
     hipDeviceProp_t prop;
-    if ((off == nullptr || off[0] == '0') && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
         fd.cus = prop.multiProcessorCount;
         constexpr int kCensus = 2048;
         uint32_t *d = nullptr;
@@ -2066,7 +2065,7 @@ int fused_capacity(const void *kern, size_t lds, int cus)
 }
 // the cache's arrival counters (created at the first fused launch on it; zero-filled once, never reset: the host tracks
 // their value)
-uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &base, uint32_t *&err)
+uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &base)
 {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     CacheHost &h = g_caches[cache];
@@ -2075,7 +2074,7 @@ uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &
         h.sync = nullptr;
     }
     if (h.sync == nullptr) {
-        const size_t words = (size_t)2 * B * kSyncLineWords + kSyncLineWords;
+        const size_t words = (size_t)2 * B * kSyncLineWords;
         if (hipMalloc(&h.sync, words * sizeof(uint32_t)) != hipSuccess || hipMemset(h.sync, 0, words * sizeof(uint32_t)) != hipSuccess) {
             (void)hipGetLastError();
             h.sync = nullptr;
@@ -2087,7 +2086,6 @@ uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &
     base = h.sync_base[kind];
     h.sync_base[kind] += arrivals;
     h.fused_launches[kind] += 1u;
-    err = h.sync + (size_t)2 * h.sync_clouds * kSyncLineWords;
     return h.sync + (size_t)kind * h.sync_clouds * kSyncLineWords;
 }
 
@@ -2107,6 +2105,7 @@ bool stack_fusable(const conv3p_stack_desc *sd, T voxel, int B, int N, const con
     if constexpr (sizeof(T) != 4) {
         return false;
     } else {
+        if ((cfg->flags & CONV3P_CACHE_FUSED_STACK) == 0) return false;   // opt-in (include/conv3p.h: measured, not a win by default)
         if (sd->hidden != 9 || (sd->in_channels != 3 && sd->in_channels != 9) || sd->n_hidden < 2 || sd->n_hidden > kStackMaxFused) return false;
         if (sd->fz * sd->fy * sd->fx > 32 || N <= kTile || N > kFusedMaxPoints) return false;
         if (scratch_cap_needed > scratch_cap) return false;
@@ -2188,7 +2187,7 @@ int stack_forward_fused(const conv3p_stack_desc *sd, const T *points, const T *i
             }
         }
         a.N = N; a.ntiles = ntiles; a.nl = nh; a.bm = bm;
-        a.sync = fused_sync(cache, B, 0, (uint32_t)(ntiles * (nh - 1)), a.base, a.err);
+        a.sync = fused_sync(cache, B, 0, (uint32_t)(ntiles * (nh - 1)), a.base);
         if (a.sync == nullptr) return CONV3P_ERR_LAUNCH;
         Scope sc(K_FORWARD, s);
         if (sd->in_channels == 3) hipLaunchKernelGGL((stack_forward_kernel<T, 3, 9>), dim3(grid_of(bm)), dim3(256), lds, s, a);
@@ -2364,7 +2363,7 @@ int stack_backward_fused(const conv3p_stack_desc *sd, const T *points, const T *
         a.top_g = G[nh - 1];
         a.ld_act = CW;
         a.ld_ext = ld_ext;
-        a.sync = fused_sync(cache, B, 1, (uint32_t)(ntiles * k), a.base, a.err);
+        a.sync = fused_sync(cache, B, 1, (uint32_t)(ntiles * k), a.base);
         if (a.sync == nullptr) return CONV3P_ERR_LAUNCH;
         Scope sc(K_BACKWARD, s);
         (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2528,10 +2527,13 @@ int conv3p_cache_fused_status(void *cache, unsigned *forward_launches, unsigned 
     }
     if (error_bits) {
         *error_bits = 0u;
-        if (sync != nullptr &&
-            hipMemcpy(error_bits, sync + (size_t)2 * clouds * kSyncLineWords, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
-            (void)hipGetLastError();
-            return CONV3P_ERR_LAUNCH;
+        if (sync != nullptr) {
+            std::vector<uint32_t> h((size_t)2 * clouds * kSyncLineWords);
+            if (hipMemcpy(h.data(), sync, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+                (void)hipGetLastError();
+                return CONV3P_ERR_LAUNCH;
+            }
+            for (size_t l = 0; l < h.size(); l += kSyncLineWords) *error_bits |= h[l + 2];
         }
     }
     return CONV3P_OK;

@@ -471,7 +471,7 @@ __device__ __forceinline__ void backward_sparse_tile(
             const uint64_t lt_lane = lane == 0 ? 0ull : (~0ull >> (64 - lane));
             Query<T> q;
             make_query(q, mine, st);
-            Window<T> win;
+            Window<T> win{};
             if (cmin != nullptr) make_window(win, mine, st, cmin + (size_t)b * 3);
             for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, 0, 1, [&](const PointRec<T> &v, int) {
                 const uint32_t fb = backward_tap(q.p, v, st, tapmap);
@@ -483,7 +483,7 @@ __device__ __forceinline__ void backward_sparse_tile(
                 T *grow = G + (size_t)slot_of(fb, lt_lane) * COUT;
 #pragma unroll
                 for (int c = 0; c < COUT; ++c) grow[c] += dyr[c] * rcp;
-            }, cmin != nullptr ? &win : nullptr);
+            }, win, cmin != nullptr);
         }
     };
     auto phase_B = [&](int t0, int t1, bool accumulate = false) {

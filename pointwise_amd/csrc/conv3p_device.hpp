@@ -296,12 +296,12 @@ __device__ __forceinline__ int axis_tap(T v, T lo, T voxel, int full, const int1
 // test (.cpp:277) followed by the tap computation (.cpp:280-290).  Returns the tap or -1.
 template <typename T>
 __device__ __forceinline__ int exact_tap(const PointRec<T> &v, const Query<T> &q, const Stencil<T> &st,
-                                         const int16_t *tapmap, const Window<T> *win = nullptr)
+                                         const int16_t *tapmap, const Window<T> &win, bool use_win)
 {
     const bool out = (v.x < q.lo[0]) | (v.x > q.hi[0]) | (v.y < q.lo[1]) | (v.y > q.hi[1]) |
                      (v.z < q.lo[2]) | (v.z > q.hi[2]);
     if (out) return -1;
-    if (win != nullptr && outside_window(v.x, v.y, v.z, win->vmin, win->cell, st)) return -1;   // .cpp:260-266
+    if (use_win && outside_window(v.x, v.y, v.z, win.vmin, win.cell, st)) return -1;   // .cpp:260-266
     const int tx = axis_tap(v.x, q.lo[0], st.voxel, st.full[0], tapmap);
     const int ty = axis_tap(v.y, q.lo[1], st.voxel, st.full[1], tapmap + st.maxfull);
     const int tz = axis_tap(v.z, q.lo[2], st.voxel, st.full[2], tapmap + 2 * st.maxfull);
@@ -458,7 +458,7 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
                                                   const T *__restrict__ cloud_box, int ntiles,
                                                   const Query<T> &q, const Stencil<T> &st,
                                                   const int16_t *tapmap, float *soa, int first, int stride,
-                                                  OnHit &&on_hit, const Window<T> *win = nullptr)
+                                                  OnHit &&on_hit, const Window<T> &win, bool use_win)   // (by reference + flag: a pointer that may be null kept the window in scratch memory)
 {
     const int lane = threadIdx.x & 63;
     const bool qvalid = q.orig >= 0;
@@ -478,7 +478,7 @@ __device__ __forceinline__ void for_each_neighbor(const PointRec<T> *__restrict_
             if (!qvalid) m0 = m1 = 0;
             for_each_bit(m0, m1, [&](int c) {
                 const PointRec<T> v = tile[c];
-                const int f = exact_tap(v, q, st, tapmap, win);
+                const int f = exact_tap(v, q, st, tapmap, win, use_win);
                 if (f >= 0) on_hit(v, f);
             });
         }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void t
             const float *zr = z_cloud + ((size_t)v.idx * st.ntap + f) * kZRow;
 #pragma unroll
             for (int c = 0; c < COUT; ++c) acc[c] = fma_t(zr[c], rcp, acc[c]);
-        }, cmin != nullptr ? &win : nullptr);
+        }, win, cmin != nullptr);
 #pragma unroll
         for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
         __syncthreads();

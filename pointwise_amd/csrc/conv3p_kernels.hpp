@@ -881,6 +881,12 @@ __device__ __forceinline__ void forward_tile(
     RowLd ld, int b, int qt, T *__restrict__ out2, int ld_out2, const Sync &sync)
 {
     constexpr bool kSmall = CIN > 0;
+    // (fused stack launch: the same code runs once per layer in one kernel; values derived from the thread index would be
+    // computed once and kept in registers across all layers -- 3 spilled registers at the 128-register cap -- unless the
+    // index is opaque to the optimiser in each pass)
+    uint32_t tid_ = threadIdx.x;
+    if constexpr (Sync::kActive) asm volatile("" : "+v"(tid_));
+    const uint32_t tid = tid_;
     const int cin = kSmall ? CIN : cin_rt;
     const int cout = kSmall ? COUT : cout_rt;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -899,7 +905,7 @@ __device__ __forceinline__ void forward_tile(
     off += align16((size_t)st.ntap * kCntStride * sizeof(T));
     int32_t *qorig = reinterpret_cast<int32_t *>(smem + off);
     off += 256;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
     T *red = reinterpret_cast<T *>(smem + off);   // [4][COUT][64], overflow path only
@@ -926,13 +932,13 @@ __device__ __forceinline__ void forward_tile(
         for (int u = 0; u < kTcPer; ++u) {
             // unconditional load from a clamped index (a predicated load gets its own exec-mask branch and a full
             // vmcnt(0) wait from hipcc: eight memory latencies in series instead of one)
-            const int e = (int)threadIdx.x + 256 * u;
+            const int e = (int)tid + 256 * u;
             tcv[u] = tc[e < st.ntap * kTile ? e : 0];
         }
     }
     if (kSmall) {
         // filter -> LDS, 8 independent loads per thread in flight (one memory latency per batch, not per element)
-        for (uint32_t e0 = threadIdx.x; e0 < (uint32_t)nw; e0 += 8 * 256) {
+        for (uint32_t e0 = tid; e0 < (uint32_t)nw; e0 += 8 * 256) {
             T v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = filter[e0 + u * 256 < (uint32_t)nw ? e0 + u * 256 : 0u];
@@ -1008,7 +1014,7 @@ __device__ __forceinline__ void forward_tile(
         if (as_rcp && tc_fits) {
 #pragma unroll
             for (int u = 0; u < kTcPer; ++u) {
-                const int e = (int)threadIdx.x + 256 * u;
+                const int e = (int)tid + 256 * u;
                 if (e < st.ntap * kTile) rcpt[(e >> 6) * kCntStride + (e & 63)] = (T)1 / (T)tcv[u];
             }
         } else {
@@ -1132,7 +1138,7 @@ __device__ __forceinline__ void forward_tile(
             } else {
                 const uint2 sg = segs[tile_id * ngroups + g];
                 const PairEntry *pe = pairs + sg.x;
-                for (uint32_t e = threadIdx.x; e < sg.y; e += blockDim.x) {
+                for (uint32_t e = tid; e < sg.y; e += blockDim.x) {
                     const PairEntry en = pe[e];
                     const uint32_t f = code_fwd(en.code);
                     if (f != kNoTap) accumulate(en.cand, f, code_q(en.code), (T)1 / (T)cnt[f * kCntStride + code_q(en.code)]);
@@ -1144,12 +1150,12 @@ __device__ __forceinline__ void forward_tile(
         const T *cloud_box = boxes + (size_t)b * ntiles * 6;
         Query<T> q;
         make_query(q, me, st);
-        Window<T> win;
+        Window<T> win{};
         if (cmin != nullptr) make_window(win, me, st, cmin + (size_t)b * 3);
         for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, wave, kWavesPerBlock,
                           [&](const PointRec<T> &v, int f) {
             accumulate((uint32_t)v.idx, (uint32_t)f, (uint32_t)lane, (T)1 / (T)cnt[f * kCntStride + lane]);
-        }, cmin != nullptr ? &win : nullptr);
+        }, win, cmin != nullptr);
     }
 
     if constexpr (kSmall) {
@@ -1186,7 +1192,7 @@ __device__ __forceinline__ void forward_tile(
 #pragma unroll
             for (int c = 0; c < COUT; ++c) red[((size_t)wave * COUT + c) * 64 + lane] = acc[c];
             __syncthreads();
-            for (int e = threadIdx.x; e < COUT * 64; e += blockDim.x) {
+            for (int e = tid; e < COUT * 64; e += blockDim.x) {
                 const int c = e >> 6;   // e & 63 == lane
                 T sum = red[((size_t)0 * COUT + c) * 64 + lane];
 #pragma unroll
@@ -1511,14 +1517,14 @@ __global__ __launch_bounds__(256) void backward_kernel(
             const T *cloud_box = boxes + (size_t)b * ntiles * 6;
             Query<T> q;
             make_query(q, me, st);
-            Window<T> win;
+            Window<T> win{};
             if (cmin != nullptr) make_window(win, me, st, cmin + (size_t)b * 3);
             for_each_neighbor(cloud_pts, cloud_box, ntiles, q, st, tapmap, soa, kSmall ? 0 : wave,
                               kSmall ? 1 : kWavesPerBlock, [&](const PointRec<T> &v, int) {
                 const uint32_t fb = backward_tap(q.p, v, st, tapmap);
                 if (fb != kNoTap && (!kSmall || (int)(fb & (kWavesPerBlock - 1)) == wave))
                     accumulate((uint32_t)v.idx, fb, (uint32_t)lane, (T)0);
-            }, cmin != nullptr ? &win : nullptr);
+            }, win, cmin != nullptr);
         }
     }
 

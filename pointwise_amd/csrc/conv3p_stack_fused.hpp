@@ -54,17 +54,17 @@ __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(
 
 struct CloudSync {
     static constexpr bool kActive = true;
-    uint32_t *cnt;       // the cloud's arrival counter (monotonic; the host tracks its value between launches)
-    uint32_t target;     // its value once every tile of the cloud has stored the rows this layer gathers
+    uint32_t *cnt;       // the cloud's line: [0] arrival counter (monotonic; the host tracks its value between launches),
+                         // [1] placement word, [2] error bits (1: a wait gave up, 2: the cloud's tiles did not share an XCC)
+    uint32_t target;     // the counter's value once every tile of the cloud has stored the rows this layer gathers
     bool do_wait, do_arrive;
-    uint32_t *err;       // [0] != 0: some wait gave up
     __device__ __forceinline__ void wait() const
     {
         if (do_wait && threadIdx.x == 0) {
             int spins = 0;
             while ((int32_t)(l2_atomic_add_ret(cnt, 0u) - target) < 0) {
                 if (++spins >= kSyncMaxSpins) {
-                    __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -98,7 +98,6 @@ template <typename T> struct StackFwdArgs {
     BlockMap bm;
     uint32_t *sync;            // [clouds][kSyncLineWords]
     uint32_t base;             // the counters' value before this launch
-    uint32_t *err;
     StackFwdLayer<T> layer[kStackMaxFused];
 };
 
@@ -106,7 +105,7 @@ template <typename T> struct StackFwdArgs {
 // residue mod 8) share an XCC -- which XCC that is varies from launch to launch (the dispatcher's round-robin does not
 // restart at XCC 0: seen on the first run of this file, which compared with the census' own table and trapped).  Tile 0 of
 // the cloud publishes {launch tag, its XCC} in word 1 of the cloud's line before it first arrives; every other tile
-// compares after its first wait (one more L2 atomic of one lane, once per launch) and sets bit 1 of the error word on a
+// compares after its first wait (one more L2 atomic of one lane, once per launch) and sets bit 1 of the line's error word on a
 // mismatch (conv3p_cache_fused_status).
 __device__ __forceinline__ void publish_placement(uint32_t *line, uint32_t tag, int qt)
 {
@@ -115,10 +114,10 @@ __device__ __forceinline__ void publish_placement(uint32_t *line, uint32_t tag, 
         asm volatile("global_atomic_swap %0, %1, off" : : "v"(line + 1), "v"(v) : "memory");
     }
 }
-__device__ __forceinline__ void check_placement(uint32_t *line, uint32_t tag, int qt, uint32_t *err)
+__device__ __forceinline__ void check_placement(uint32_t *line, uint32_t tag, int qt)
 {
     if (qt != 0 && threadIdx.x == 0 && l2_atomic_add_ret(line + 1, 0u) != ((tag << 4) | xcc_id()))
-        __hip_atomic_fetch_or(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(line + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // hidden layers 0 .. nl-1 of the stack; layer 0 has CIN0 inputs, the others H
@@ -131,16 +130,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
     publish_placement(cnt, a.base, qt);
     {
         const StackFwdLayer<T> &L = a.layer[0];
-        const CloudSync sy{cnt, a.base, false, a.nl > 1, a.err};
+        const CloudSync sy{cnt, a.base, false, a.nl > 1};
         forward_tile<T, CIN0, H>(a.pts, a.boxes, L.count, L.pairs, L.segs, L.qsegs, L.input, L.filter, L.st, a.N, a.ntiles, 1, CIN0, H,
-                                 L.output, 1, a.cmin, L.tcount, L.ld, b, qt, L.out2, L.ld_out2, sy);
+                                 L.output, 1, static_cast<const T *>(nullptr), L.tcount, L.ld, b, qt, L.out2, L.ld_out2, sy);
     }
     for (int l = 1; l < a.nl; ++l) {
         const StackFwdLayer<T> &L = a.layer[l];
-        const CloudSync sy{cnt, a.base + (uint32_t)(a.ntiles * l), true, l + 1 < a.nl, a.err};
+        const CloudSync sy{cnt, a.base + (uint32_t)(a.ntiles * l), true, l + 1 < a.nl};
         forward_tile<T, H, H>(a.pts, a.boxes, L.count, L.pairs, L.segs, L.qsegs, L.input, L.filter, L.st, a.N, a.ntiles, 1, H, H,
-                              L.output, 1, a.cmin, L.tcount, L.ld, b, qt, L.out2, L.ld_out2, sy);
-        if (l == 1) check_placement(cnt, a.base, qt, a.err);
+                              L.output, 1, static_cast<const T *>(nullptr), L.tcount, L.ld, b, qt, L.out2, L.ld_out2, sy);
+        if (l == 1) check_placement(cnt, a.base, qt);
     }
 }
 
@@ -162,7 +161,6 @@ template <typename T> struct StackBwdArgs {
     BlockMap bm;
     uint32_t *sync;
     uint32_t base;
-    uint32_t *err;
     // the gradient that enters the deepest layer: g_top = ext_top * selu'(act_top), dense [B][N][H]
     const T *top_act, *top_ext;
     T *top_g;
@@ -195,16 +193,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             const size_t r = (size_t)b * a.N + orig;
             for (int c = wave; c < H; c += kWavesPerBlock) a.top_g[r * H + c] = a.top_ext[r * a.ld_ext + c] * selu_slope(a.top_act[r * a.ld_act + c]);
         }
-        const CloudSync s0{cnt, a.base, false, true, a.err};
+        const CloudSync s0{cnt, a.base, false, true};
         s0.arrive();
     }
     for (int l = 0; l < a.nl; ++l) {
         const StackBwdLayer<T> &L = a.layer[l];
-        const CloudSync sy{cnt, a.base + (uint32_t)(a.ntiles * (l + 1)), true, l + 1 < a.nl, a.err};
+        const CloudSync sy{cnt, a.base + (uint32_t)(a.ntiles * (l + 1)), true, l + 1 < a.nl};
         backward_sparse_tile<T, H, H, false>(a.pts, a.boxes, L.count, L.pairs, L.segs, L.qsegs, L.qbm, static_cast<const uint32_t *>(nullptr),
                                              L.grad_out, L.input, L.filter, L.st, a.N, a.ntiles, 1, L.grad_input, L.partials, 1, L.addend,
-                                             a.cmin, L.ld, L.cap, true, b, qt, blockIdx.x, sy);
-        if (l == 0) check_placement(cnt, a.base, qt, a.err);
+                                             static_cast<const T *>(nullptr), L.ld, L.cap, true, b, qt, blockIdx.x, sy);
+        if (l == 0) check_placement(cnt, a.base, qt);
     }
 }
 

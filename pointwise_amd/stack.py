@@ -34,7 +34,7 @@ def _side_stream(device):
 
 class Conv3pStack:
     def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234,
-                 use_cache=True, overlap_search=True, fuse_selu=True, c_stack=True):
+                 use_cache=True, overlap_search=True, fuse_selu=True, c_stack=True, fused_launch=False):
         """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers).
         use_cache: keep the geometry (sorted points, populations, neighbour lists) of each layer's stencil in
         a NeighborCache so that the search runs once per (points, stride) instead of once per op call.
@@ -43,6 +43,9 @@ class Conv3pStack:
         buffer.  Needs use_cache and fuse_selu; shapes outside the register-resident list fall back to the op-by-op
         composition below (same results)."""
         self.use_cache = use_cache
+        # fused_launch (opt-in, needs c_stack): the hidden layers of a pass as ONE launch with per-cloud barriers
+        # (CONV3P_CACHE_FUSED_STACK, csrc/conv3p_stack_fused.hpp); measured: not a win by default (include/conv3p.h)
+        self.fused_launch = fused_launch
         # None: the backward kernel of the dilated layers is chosen on the device from the lists themselves; True / False:
         # the CONV3P_CACHE_SPARSE / DENSE_NEIGHBOURHOODS hint for the stack's caches, set by tune() (or by hand before the
         # first batch) -- saves one empty launch per dilated layer and step
@@ -249,7 +252,8 @@ class Conv3pStack:
                 self._join_side(points.device)
                 self._pending.pop(idx, None)
             c = op.NeighborCache(B, N, points.dtype, points.device, slots=len(self.layers), max_taps=27,
-                                 max_cin=cmax, max_cout=cmax, sparse_neighbourhoods=self.sparse_neighbourhoods)
+                                 max_cin=cmax, max_cout=cmax, sparse_neighbourhoods=self.sparse_neighbourhoods,
+                                 fused_stack=self.fused_launch)
             self._caches[idx] = c
         return c
 
@@ -281,7 +285,8 @@ class Conv3pStack:
                 if c is None or not c.fits(B, N, self.dtype, self.device, 27, cmax, cmax):
                     self._caches[idx] = op.NeighborCache(B, N, self.dtype, self.device, slots=len(self.layers),
                                                          max_taps=27, max_cin=cmax, max_cout=cmax,
-                                                         sparse_neighbourhoods=self.sparse_neighbourhoods)
+                                                         sparse_neighbourhoods=self.sparse_neighbourhoods,
+                                                         fused_stack=self.fused_launch)
 
     def _cache_for(self, points):
         if not self.use_cache:

@@ -971,6 +971,43 @@ def test_stack_fused_selu_matches_unfused(dev):
     assert rel_err(res[1][2], res[0][2]) <= 2e-6
 
 
+@pytest.mark.parametrize("cin,ncls,B,N,kind", [(3, None, 11, 700, "modelnet"), (3, None, 32, 2048, "modelnet"), (9, 13, 3, 4096, "room"),
+                                                (9, None, 2, 1000, "lattice")])
+def test_fused_stack_launch_equals_the_per_layer_launches(dev, cin, ncls, B, N, kind):
+    """CONV3P_CACHE_FUSED_STACK (opt-in): the hidden layers of a pass as ONE launch with per-cloud barriers between the
+    layers (csrc/conv3p_stack_fused.hpp).  The tile passes are the per-layer kernels' own code: activations and grad_input
+    bit for bit those of the per-layer launches, grad_filter within the op's tolerance (its partials are summed in another
+    order); the launches are counted, no barrier wait gave up, every cloud's tiles shared an XCC; twice in a row (the
+    counters are never reset) and against the oracle."""
+    P = synth.modelnet_like(B, N, seed=5) if kind == "modelnet" else synth.room_like(B, N, 5) if kind == "room" else make_case("lattice", B, N, cin, 9, seed=5)[0]
+    X = synth.features(B, N, cin, 6, points=P)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tp, tx = t(P), t(X)
+    ups = [synth.upstream_grad(B, N, ncls if ncls else stack.HIDDEN, 70 + i) for i in range(1 if ncls else 4)]
+    res = []
+    for fused in (True, False):
+        st = stack.Conv3pStack(cin, ncls, device=dev, seed=3, fused_launch=fused)
+        st.sparse_neighbourhoods = True if kind != "room" else None     # (the fused backward needs the SPARSE hint)
+        for rep in range(2):
+            acts = st.forward(tp, tx)
+            dx, fg = st.backward([t(u) for u in ups])
+        f, b, e = st.fused_status()
+        assert e == 0, "fused launch error bits %d" % e
+        assert (f, b) == ((2, 2 if kind != "room" else 0) if fused else (0, 0))
+        res.append(([a.clone() for a in acts], dx.clone(), fg.clone()))
+    for a, r in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, r)
+    assert torch.equal(res[0][1], res[1][1])
+    assert rel_err(res[0][2].cpu().numpy(), res[1][2].cpu().numpy()) <= 2e-6
+    if N <= 1000:
+        st = stack.Conv3pStack(cin, ncls, device=dev, seed=3)
+        ref_acts, ref_dx, ref_fused = _oracle_stack(P, X, [f.cpu().numpy() for f in st.filters], st.layers, ups, ncls)
+        for a, r in zip(res[0][0], ref_acts):
+            assert rel_err(a.cpu().numpy(), r) <= 2e-5
+        assert rel_err(res[0][1].cpu().numpy(), ref_dx) <= 5e-5
+        assert rel_err(res[0][2].cpu().numpy(), ref_fused) <= 5e-5
+
+
 def test_cache_prepare_multi_equals_per_stencil_prepare(dev):
     """One batched search launch for strides 1..4 gives the same lists (hence bitwise the same op results) as
     four separate prepares; a second multi call on unchanged points launches nothing new and stays valid."""

@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 B, N, cin, ncls = 16, 4096, 9, 13
 Ps = [torch.from_numpy(synth.room_like(B, N, 40 + i)).to(dev) for i in range(3)]
 Xs = [torch.from_numpy(synth.features(B, N, cin, 50 + i, points=p.cpu().numpy())).to(dev) for i, p in enumerate(Ps)]
-st = stack.Conv3pStack(cin, ncls, device=dev, seed=3)
+st = stack.Conv3pStack(cin, ncls, device=dev, seed=3, fused_launch="--fused" in sys.argv)
 if "--no-tune" not in sys.argv:
     st.tune(Ps[0])
 if "--sparse" in sys.argv:   # developer: the populated-rows backward for the dilated layers whatever the lists look like

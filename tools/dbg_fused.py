@@ -11,7 +11,7 @@ def run(cin, ncls, B, N, kind, tune):
     tp, tx = t(P), t(X)
     res = []
     for c_stack in (True, False):
-        st = stack.Conv3pStack(cin, ncls, device=dev, seed=3, c_stack=c_stack)
+        st = stack.Conv3pStack(cin, ncls, device=dev, seed=3, c_stack=c_stack, fused_launch=c_stack)
         if tune:
             st.tune(tp)
         print("  c_stack", c_stack, "sparse", st.sparse_neighbourhoods, flush=True)
