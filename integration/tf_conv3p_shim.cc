@@ -15,10 +15,17 @@
 //     read without the blocking cudaMemcpy D2H of tf_conv3p_atrous.cu:577,586;
 //   * a shape function is attached (the reference registers none);
 //   * DEFAULT: the neighbour geometry lives in a persistent cache tensor per (device, B, N, dtype, taps) -- a
-//     process-global map, allocate_persistent, the conv3p_*_cached_* entry points WITHOUT any caller hint: every
-//     call re-validates the points on the device (content hash), so TF's buffer reuse cannot make it stale, and
-//     the 8 op calls of a model step share one sort and one search per stride instead of 8 + 8
-//     (bench.py: op_boundary_cached_ms_per_step vs stateless_ms_per_step);
+//     process-global map, allocate_persistent, the conv3p_*_cached_* entry points.  The Python caller gives no hint.
+//     The shim derives one from TensorFlow's own guarantees: it KEEPS A REFERENCE to the `points` tensor it validated
+//     last (a Tensor copy shares and reference-counts the TensorBuffer).  While that reference is held the allocator
+//     cannot hand the buffer to anyone else, and a buffer with more than one reference is never written in place
+//     (input tensors are immutable values; in-place forwarding needs a reference count of one).  A call whose `points`
+//     shares that very buffer (same bytes: Tensor::SharesBufferWith + equal data pointer and size) therefore sees
+//     unchanged content and passes CONV3P_CACHE_POINTS_UNCHANGED -- no hash launch and none of the three launches
+//     that would find nothing to do (21 us per op call on cfg2).  Any other `points` is validated on the device by
+//     content hash as before and becomes the held one: the first op of a step pays one hash + sort + one search launch
+//     for all strides, the other seven nothing (bench.py: op_boundary_native_ms_per_step, and
+//     op_boundary_native_unhinted_ms_per_step for -DCONV3P_SHIM_NO_IDENTITY_HINT, every call hashed);
 //   * -DCONV3P_SHIM_STATELESS: the stateless entry points, scratch from one allocate_temp per Compute
 //     (conv3p_workspace_bytes), nothing kept between calls.
 #include <map>
@@ -94,7 +101,23 @@ struct CacheSlot {
     PersistentTensor tensor;
     size_t bytes = 0;
     conv3p_cache_config cfg{};
+    Tensor held_points;        // the points tensor whose content the cache was last validated against (reference held)
 };
+
+// flags for this call: CONV3P_CACHE_POINTS_UNCHANGED iff `points` IS the buffer validated last (see the file header)
+int FlagsFor(CacheSlot *cs, const Tensor &points, const void *data)
+{
+#ifdef CONV3P_SHIM_NO_IDENTITY_HINT
+    (void)cs; (void)points; (void)data;
+    return 0;
+#else
+    if (cs->held_points.IsInitialized() && cs->held_points.SharesBufferWith(points) &&
+        cs->held_points.flat<int8>().data() == static_cast<const int8 *>(data) && cs->held_points.TotalBytes() == points.TotalBytes())
+        return CONV3P_CACHE_POINTS_UNCHANGED;
+    cs->held_points = points;  // drops the reference to the previous batch's tensor
+    return 0;
+#endif
+}
 typedef std::tuple<const void *, int, int, int, int> CacheKey;
 std::mutex g_cache_mu;
 std::map<CacheKey, CacheSlot> g_cache;
@@ -113,8 +136,8 @@ char *CacheFor(OpKernelContext *ctx, int elem, int B, int N, int taps, int Cin, 
         cfg.pairs_per_point = 0;             // default capacity
         cfg.max_Cin = Cin > cs.cfg.max_Cin ? Cin : cs.cfg.max_Cin;
         cfg.max_Cout = Cout > cs.cfg.max_Cout ? Cout : cs.cfg.max_Cout;
-        cfg.flags = 0;                       // never CONV3P_CACHE_POINTS_UNCHANGED: TF promises nothing between ops; no kernel
-                                             // hint either: the library picks the backward kernel on the device from the lists
+        cfg.flags = 0;                       // per call: CONV3P_CACHE_POINTS_UNCHANGED only by FlagsFor(); no kernel hint: the
+                                             // library picks the backward kernel on the device from the lists
         const size_t need = conv3p_cache_bytes(elem, B, N, &cfg);
         if (need == 0) {
             ctx->CtxFailure(errors::InvalidArgument("Conv3p: cannot size the neighbour cache"));
@@ -146,6 +169,7 @@ char *CacheFor(OpKernelContext *ctx, int elem, int B, int N, int taps, int Cin, 
         }
         cs.bytes = need;
         cs.cfg = cfg;
+        cs.held_points = Tensor();   // a new cache buffer has validated nothing yet
     }
     *slot = &cs;
     char *p = reinterpret_cast<char *>(cs.tensor.AccessTensor(ctx)->flat<int8>().data());
@@ -189,9 +213,11 @@ template <typename T> class Conv3pHipOp : public OpKernel {
         CacheSlot *cs = nullptr;
         char *cp = CacheFor(ctx, Abi<T>::kElem, B, N, fz * fy * fx, Cin, Cout, &cs);
         if (cp == nullptr) return;
+        conv3p_cache_config cfg = cs->cfg;
+        cfg.flags |= FlagsFor(cs, points, points.flat<T>().data());
         const int rc = Abi<T>::forward_cached(points.flat<T>().data(), input.flat<T>().data(), filter.flat<T>().data(),
                                               stride.flat<int32>().data() /* host memory */, voxel.flat<T>()(0), B, N,
-                                              Cin, Cout, fz, fy, fx, out->flat<T>().data(), cp, cs->bytes, &cs->cfg,
+                                              Cin, Cout, fz, fy, fx, out->flat<T>().data(), cp, cs->bytes, &cfg,
                                               StreamOf(ctx));
 #else
         const size_t need = conv3p_workspace_bytes(CONV3P_PASS_FORWARD, Abi<T>::kElem, B, N, Cin, Cout, fz, fy, fx);
@@ -230,10 +256,12 @@ template <typename T> class Conv3pGradHipOp : public OpKernel {
         CacheSlot *cs = nullptr;
         char *cp = CacheFor(ctx, Abi<T>::kElem, B, N, fz * fy * fx, Cin, Cout, &cs);
         if (cp == nullptr) return;
+        conv3p_cache_config cfg = cs->cfg;
+        cfg.flags |= FlagsFor(cs, points, points.flat<T>().data());
         const int rc = Abi<T>::backward_cached(grad.flat<T>().data(), points.flat<T>().data(), input.flat<T>().data(),
                                                filter.flat<T>().data(), stride.flat<int32>().data(), voxel.flat<T>()(0),
                                                B, N, Cin, Cout, fz, fy, fx, dx->flat<T>().data(), dw->flat<T>().data(), cp,
-                                               cs->bytes, &cs->cfg, StreamOf(ctx));
+                                               cs->bytes, &cfg, StreamOf(ctx));
 #else
         const size_t need = conv3p_workspace_bytes(CONV3P_PASS_BACKWARD, Abi<T>::kElem, B, N, Cin, Cout, fz, fy, fx);
         Tensor ws;

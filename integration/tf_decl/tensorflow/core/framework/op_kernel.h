@@ -44,6 +44,12 @@ class Tensor {
     const TensorShape &shape() const;
     template <typename T> FlatView<T> flat();
     template <typename T> FlatView<const T> flat() const;
+    // tensorflow/core/framework/tensor.h: copies share (and reference-count) the underlying TensorBuffer
+    Tensor(const Tensor &other);
+    Tensor &operator=(const Tensor &other);
+    bool IsInitialized() const;
+    bool SharesBufferWith(const Tensor &b) const;
+    std::size_t TotalBytes() const;
 };
 
 namespace se_decl {   // stream_executor::Stream -> platform stream handle (ROCm build: a hipStream_t)

@@ -52,8 +52,16 @@ class NeighborCache:
     is decided on the device by content hash, so reusing it with different clouds is always safe."""
 
     def __init__(self, B, N, dtype, device, slots=5, max_taps=27, pairs_per_point=0, max_cin=36, max_cout=41,
-                 sparse_neighbourhoods=None, fused_stack=False):
+                 sparse_neighbourhoods=None, fused_stack=False, trust_tensor_identity=False):
         lib = _lib.load()
+        # trust_tensor_identity (opt-in; what integration/tf_conv3p_shim.cc does with TensorFlow's tensors): the cache keeps
+        # a REFERENCE to the points tensor it validated last; a later op call whose `points` is that very storage, at the
+        # same address, shape and torch version counter (every in-place write through torch bumps it, and a storage that
+        # is referenced cannot be recycled) carries CONV3P_CACHE_POINTS_UNCHANGED by itself -- no hash launch and none of
+        # the three launches that would find nothing to do.  Code that writes the buffer behind torch's back (a foreign
+        # kernel) must call forget_points() or leave this off.
+        self.trust_tensor_identity = trust_tensor_identity
+        self._held = None
         self.fused_stack = fused_stack   # CONV3P_CACHE_FUSED_STACK for the stack-level entry points (opt-in)
         self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout, 0)
         # None: the library decides on the device which backward kernel serves the dilated narrow layers; True / False:
@@ -76,6 +84,20 @@ class NeighborCache:
                          (_lib.CACHE_PREPARE_DEEP_ORDERS if deep_orders else 0) | \
                          (_lib.CACHE_FUSED_STACK if self.fused_stack else 0)
         return ctypes.addressof(self.cfg)
+
+    def identity_hint(self, points):
+        """True iff `points` is the tensor this cache validated last, unmodified (see trust_tensor_identity)."""
+        if not self.trust_tensor_identity:
+            return False
+        key = (points.data_ptr(), points.untyped_storage().data_ptr(), int(points._version), tuple(points.shape), points.dtype)
+        held = self._held
+        if held is not None and held[1] == key and int(held[0]._version) == key[2]:
+            return True
+        self._held = (points, key)
+        return False
+
+    def forget_points(self):
+        self._held = None
 
     def fits(self, B, N, dtype, device, ntap, cin, cout):
         return (self.key == (int(B), int(N), dtype, torch.device(device)) and ntap <= self.cfg.max_taps
@@ -176,8 +198,8 @@ def conv3p(points, input, filter, stride, voxel_size, cache=None, points_unchang
             _call(getattr(lib, ("conv3p_layer_forward_cached_" if _fused_selu else "conv3p_forward_cached_") + sfx),
                   points.data_ptr(), input.data_ptr(),
                   filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx,
-                  out.data_ptr(), cache.buf.data_ptr(), cache.nbytes, cache.cfg_ptr(points_unchanged),
-                  stream.cuda_stream)
+                  out.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
+                  cache.cfg_ptr(points_unchanged or cache.identity_hint(points)), stream.cuda_stream)
         else:
             if _fused_selu:
                 raise Conv3pInvalidArgument("conv3p_layer needs a NeighborCache that fits these clouds")
@@ -230,12 +252,12 @@ def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_
                       points.data_ptr(), input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p),
                       creal(vox), B, N, Cin, Cout, fz, fy, fx, add.data_ptr() if add is not None else None,
                       dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
-                      cache.cfg_ptr(points_unchanged), stream.cuda_stream)
+                      cache.cfg_ptr(points_unchanged or cache.identity_hint(points)), stream.cuda_stream)
             else:
                 _call(getattr(lib, "conv3p_backward_cached_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
                       input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
                       Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
-                      cache.cfg_ptr(points_unchanged), stream.cuda_stream)
+                      cache.cfg_ptr(points_unchanged or cache.identity_hint(points)), stream.cuda_stream)
         else:
             if _fused_selu:
                 raise Conv3pInvalidArgument("conv3p_layer_grad needs a NeighborCache that fits these clouds")

@@ -473,9 +473,10 @@ template <typename T> int run_prep(const T *points, const Call<T> &c)
 
 template <typename T> size_t search_lds_bytes(const Stencil<T> &st, int gtiles)
 {
+    // (+ 512: search_tile's static array of the centres' backward-tap sets -- it counts against the 160 KiB like the dynamic part)
     return lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) + 64 * 3 * 4 +
            a16((size_t)gtiles * 64 * 8) + a16((size_t)gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
-           a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4);
+           a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4) + 512;
 }
 
 // grid origin of every cloud, for stencils whose candidate window can decide (even dilated extents)

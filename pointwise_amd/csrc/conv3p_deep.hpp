@@ -741,31 +741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
 #pragma unroll
                     for (int j = 0; j < CPW; ++j) bv[s2][j] = Bf[(size_t)(2 * s2) * NDIM + j * (CSTEP * 32)];
             };
-#ifdef DEEP_DEV_FILLER
-            float4 fv[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-#endif
             auto mma_g = [&](int gi, const float (&bv)[KG][CPW]) {
-#ifdef DEEP_DEV_FILLER   // developer experiment: independent gather + vector-ALU work inside every k-group (does it hide?)
-                {
-                    const char *sb = reinterpret_cast<const char *>(src_cloud);
-                    float fs[4] = {badsum, badsum, badsum, badsum};
-#pragma unroll
-                    for (int r2 = 0; r2 < DEEP_DEV_FILLER; ++r2)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {   // (consumes the rows requested one k-group earlier)
-                            fs[0] = __builtin_fmaf(fv[u].x, 1.0001f, fs[0]); fs[1] = __builtin_fmaf(fv[u].y, 1.0001f, fs[1]);
-                            fs[2] = __builtin_fmaf(fv[u].z, 1.0001f, fs[2]); fs[3] = __builtin_fmaf(fv[u].w, 1.0001f, fs[3]);
-                        }
-                    badsum += ((fs[0] + fs[1]) + (fs[2] + fs[3])) * 0.0f;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        // one whole row per wave instruction, as stage 1 reads them (K = 256: 64 lanes x 16 bytes)
-                        const uint32_t idx = (uint32_t)((gi * 4 + u) * 977 + (int)blockIdx.x * 131 + wave * 17) % (uint32_t)N;
-                        const float4_a4 t4 = *reinterpret_cast<const float4_a4 *>(sb + (size_t)idx * (uint32_t)kreal * 4u + ((lane * 16u) % ((uint32_t)kreal * 4u)));
-                        fv[u] = make_float4(t4.x, t4.y, t4.z, t4.w);
-                    }
-                }
-#endif
                 const float *arow = Al + (gi / GPT) * 64 * LDA + (gi % GPT) * (2 * KG);
 #pragma unroll
                 for (int s2 = 0; s2 < KG; ++s2) {

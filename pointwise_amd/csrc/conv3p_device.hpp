@@ -610,7 +610,8 @@ __device__ __forceinline__ LaneShare share_lanes(uint2 seg, uint32_t *scratch)
     ls.r = lane - h;
     ls.n = span >> 8;
     ls.seg = make_uint2(scratch[80 + 2 * ls.cl], scratch[81 + 2 * ls.cl]);
-    if (ls.r >= ls.n) {   // lanes past the last centre's share
+    if (ls.r >= ls.n) {   // lanes past the last centre's share: idle (no records, first index 0)
+        ls.r = 0u;
         ls.n = 0u;
         ls.seg.y = 0u;
     }

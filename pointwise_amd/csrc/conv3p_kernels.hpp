@@ -853,9 +853,10 @@ __device__ __forceinline__ f32x2 lds_read_b64(const float *p) { return *(lds_cv_
 // ---------------------------------------------------------------------------------
 // forward accumulate: out[i,c] = sum over pairs of W[f,k,c] * x[j,k] / count[i,f]  (.cpp:480-494)
 // One workgroup = one query tile; threads stride over the tile's pair segment (lane = pair).
-// Small path (CIN/COUT compile-time): each wave owns 16 centres, the 4 lanes {c, c+16, c+32, c+48}
-// walk centre c's list 4 records at a time; filter in LDS, output row in registers, the 4 partial
-// rows combined by a fixed shuffle butterfly (bitwise reproducible).  Generic path: thread = pair,
+// Small path (CIN/COUT compile-time): each wave owns 16 centres; its 64 lanes are dealt to them in proportion to their
+// lists (share_lanes: consecutive lanes per centre, lane r of a centre's n lanes walks records r, r + n, ...); filter in
+// LDS, output row in registers, the partial rows of a centre's lanes summed through LDS in ascending lane order
+// (bitwise reproducible).  Generic path: thread = pair,
 // global atomics into the zeroed output.
 // A segment marked kSegOverflow makes the workgroup search its query tile itself.
 // ---------------------------------------------------------------------------------
@@ -1067,8 +1068,8 @@ __device__ __forceinline__ void forward_tile(
     if (!overflow) {
         for (int g = 0; g < ngroups; ++g) {
             if constexpr (kSmall) {
-                // wave w owns the centres 16w..16w+15; the 4 lanes {c, c+16, c+32, c+48} share centre c and
-                // read 4 consecutive pair records per step (64 contiguous bytes)
+                // wave w owns the centres 16w..16w+15; a centre's lanes (consecutive, share_lanes; four per centre when the
+                // cloud was searched in several groups) read consecutive pair records per step
                 // Software pipeline over NS NAMED slots (the loop is unrolled by NS so that a slot is a fixed
                 // set of registers): the record of step k+2 and the neighbour row of step k+1 are in flight while
                 // step k runs its 81 FMAs.  Rotating the slots by register copies would make every step wait for
@@ -1233,9 +1234,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
 //   count = population of tap f' of ii, pair skipped when 0 (.cpp:678-679),
 //   g[c] = dY[ii,c] / count,  dX[j,k] += g[c] W[f',k,c],  dW[f',k,c] += g[c] X[j,k].
 // Small path (one workgroup = one query tile):
-//   phase A  each wave owns 16 centres; the 4 lanes {c, c+16, c+32, c+48} walk centre c's pair list 4
-//            records per step:  G[(f',c)][j] += dY[ii,c] * (1/count)   (LDS [row][65]; sub-lanes that
-//            meet on one tap take turns in a fixed order -> no atomics, reproducible)
+//   phase A  each wave owns 16 centres; its lanes are dealt to them in proportion to their lists (share_lanes), every
+//            lane walks ONE run of its centre's list:  G[(f',c)][j] += dY[ii,c] * (1/count)   (LDS [row][65]; lanes of
+//            a centre that meet on one tap take turns, lower lane first -> no atomics, reproducible)
 //   phase B  thread = row (f',c):  dW[f',k,c] = sum_j G[row][j] * X[j,k]  -> this workgroup's
 //            partial slot (X tile broadcast from LDS)
 //   phase C  lane = centre j, waves split the rows:  dX[j,k] = sum_row G[row][j] * W[row][k],

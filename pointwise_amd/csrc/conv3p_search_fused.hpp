@@ -602,6 +602,10 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         });
         if (have > 0) drain(have);
     }
+    // (the compaction below lets wave w read and rewrite records the OTHER waves stored to global memory in pass 2: their
+    // stores must have left the waves before the barrier -- a workgroup-scope release; all four waves share the CU's one
+    // vector L1, the default non-tgsplit mode, so nothing more is needed for them to be read back)
+    __threadfence_block();
     __syncthreads();
 
     // ---- compaction (round 5).  The tables are a superset filter: on the models' dilated stencils a third of the

@@ -575,6 +575,41 @@ def test_cache_serves_several_voxel_sizes_over_the_same_points(dev, slots):
         assert rel_err(dx.cpu().numpy(), dx_ref) <= 1e-5 and rel_err(dw.cpu().numpy(), dw_ref) <= 2e-5, (vox, s)
 
 
+def test_cache_that_trusts_tensor_identity_still_tracks_content(dev):
+    """trust_tensor_identity (what the TF shim does with TensorFlow's tensors): calls on the very tensor the cache validated
+    last -- same storage, address, shape, torch version counter -- skip the content hash; an in-place write through torch
+    (version bump), another tensor, or a recycled address (the reference held by the cache makes that impossible while it
+    is the held one; here: a new tensor after the old one was dropped) are all validated again.  Results bit for bit the
+    stateless ones throughout."""
+    B, N = 3, 600
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=2, max_taps=27, max_cin=9, max_cout=9, trust_tensor_identity=True)
+    P1, X, W, dY = make_case("modelnet", B, N, 9, 9, seed=830)
+    P2 = make_case("modelnet", B, N, 9, 9, seed=831)[0]
+    tx, tw, tdy = [torch.from_numpy(a).to(dev) for a in (X, W, dY)]
+    tp = torch.from_numpy(P1).to(dev)
+
+    def check(tpts):
+        for s in ((2, 2, 2), (1, 1, 1), (2, 2, 2)):
+            y_c = op.conv3p(tpts, tx, tw, s, VOX, cache=cache)
+            dx_c, dw_c = op.conv3p_grad(tdy, tpts, tx, tw, s, VOX, cache=cache)
+            y_s = op.conv3p(tpts, tx, tw, s, VOX)
+            dx_s, dw_s = op.conv3p_grad(tdy, tpts, tx, tw, s, VOX)
+            assert torch.equal(y_c, y_s) and torch.equal(dx_c, dx_s) and torch.equal(dw_c, dw_s)
+    check(tp)
+    assert cache.identity_hint(tp)                       # the same tensor again: trusted
+    tp.copy_(torch.from_numpy(P2))                       # in-place write through torch: version bump
+    assert not cache.identity_hint(tp)
+    cache.forget_points()
+    check(tp)
+    other = torch.from_numpy(P1).to(dev)                 # another tensor
+    check(other)
+    del other
+    torch.cuda.empty_cache()
+    fresh = torch.from_numpy(P2).to(dev)                 # may well land on the address `other` had
+    check(fresh)
+    check(tp)
+
+
 def test_cache_garbage_buffer_is_harmless(dev):
     """A cache whose bytes are garbage (never zero-filled, or recycled) can only cost a rebuild."""
     B, N = 2, 256

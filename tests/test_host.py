@@ -179,3 +179,15 @@ def test_no_kernel_of_the_library_spills_vector_registers():
         assert any(must in n for n in names), must + ": kernel not found in the code object"
     spilled = [(n, vs) for n, _, vs, _, _ in res if vs != 0]
     assert not spilled, spilled
+    # ... and no private segment at all (no dynamically indexed local array, no struct that went through memory) in the
+    # models' forward kernels, the dense backward, the fused stack kernels and the matrix-core kernels.  (Round 6: the
+    # forward kernels' 28 bytes were a Window struct behind a pointer that may be null; what is left, and listed here so
+    # that it cannot grow unnoticed: 16 bytes of dead stores -- a uint2 member written on two paths, never re-loaded --
+    # in the populated-rows backward, 36 in the tile-pair search of even extents.)
+    allowed = {"backward_sparse_kernel": 16, "search_kernel": 36}
+    private = [(n, sc) for n, _, _, _, sc in res if sc > max([v for k, v in allowed.items() if k in n] + [0])]
+    assert not private, private
+    for must0 in ("forward_kernelIfLi3ELi9E", "forward_kernelIfLi9ELi9E", "forward_kernelIfLi12ELi9E", "forward_kernelIfLi36ELi13E",
+                  "backward_kernelIfLi3ELi9E", "backward_kernelIfLi9ELi9E", "stack_forward_kernelIfLi3ELi9E", "stack_backward_kernelIfLi9E"):
+        hit = [sc for n, _, _, _, sc in res if must0 in n]
+        assert hit and max(hit) == 0, (must0, hit)
