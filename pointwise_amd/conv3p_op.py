@@ -85,8 +85,9 @@ class NeighborCache:
                          (_lib.CACHE_FUSED_STACK if self.fused_stack else 0)
         return ctypes.addressof(self.cfg)
 
-    def identity_hint(self, points):
-        """True iff `points` is the tensor this cache validated last, unmodified (see trust_tensor_identity)."""
+    def _identity_hint(self, points):
+        """True iff `points` is the tensor this cache validated last, unmodified (see trust_tensor_identity); otherwise it
+        becomes the held one -- to be called only by an op call that then validates it on the device."""
         if not self.trust_tensor_identity:
             return False
         key = (points.data_ptr(), points.untyped_storage().data_ptr(), int(points._version), tuple(points.shape), points.dtype)
@@ -199,7 +200,7 @@ def conv3p(points, input, filter, stride, voxel_size, cache=None, points_unchang
                   points.data_ptr(), input.data_ptr(),
                   filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin, Cout, fz, fy, fx,
                   out.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
-                  cache.cfg_ptr(points_unchanged or cache.identity_hint(points)), stream.cuda_stream)
+                  cache.cfg_ptr(points_unchanged or cache._identity_hint(points)), stream.cuda_stream)
         else:
             if _fused_selu:
                 raise Conv3pInvalidArgument("conv3p_layer needs a NeighborCache that fits these clouds")
@@ -252,12 +253,12 @@ def conv3p_grad(grad_from_next, points, input, filter, stride, voxel_size, grad_
                       points.data_ptr(), input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p),
                       creal(vox), B, N, Cin, Cout, fz, fy, fx, add.data_ptr() if add is not None else None,
                       dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
-                      cache.cfg_ptr(points_unchanged or cache.identity_hint(points)), stream.cuda_stream)
+                      cache.cfg_ptr(points_unchanged or cache._identity_hint(points)), stream.cuda_stream)
             else:
                 _call(getattr(lib, "conv3p_backward_cached_" + sfx), grad_from_next.data_ptr(), points.data_ptr(),
                       input.data_ptr(), filter.data_ptr(), ctypes.cast(s3, ctypes.c_void_p), creal(vox), B, N, Cin,
                       Cout, fz, fy, fx, dx.data_ptr(), dw.data_ptr(), cache.buf.data_ptr(), cache.nbytes,
-                      cache.cfg_ptr(points_unchanged or cache.identity_hint(points)), stream.cuda_stream)
+                      cache.cfg_ptr(points_unchanged or cache._identity_hint(points)), stream.cuda_stream)
         else:
             if _fused_selu:
                 raise Conv3pInvalidArgument("conv3p_layer_grad needs a NeighborCache that fits these clouds")
