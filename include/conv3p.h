@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CONV3P_ABI_VERSION 4
+#define CONV3P_ABI_VERSION 5
 
 /* status codes */
 #define CONV3P_OK 0

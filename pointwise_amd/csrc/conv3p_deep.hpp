@@ -735,7 +735,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             const float *Al = A + myrow * LDA + (lane >> 5);
             auto load_g = [&](int gi, float (&bv)[KG][CPW]) {
                 const int gc = gi < ng ? gi : ng - 1;
+#ifdef DEEP_DEV_B_L1   // developer timing probe (wrong results): every B-operand group is the SAME 2 KG rows -- L1 hits instead of L2 traffic
+                const float *Bf = Bl + (size_t)(gc & 0) * NDIM;
+#else
                 const float *Bf = Bl + (size_t)taps[t0 + gc / GPT] * KDIM * NDIM + (size_t)(gc % GPT) * (2 * KG) * NDIM;
+#endif
 #pragma unroll
                 for (int s2 = 0; s2 < KG; ++s2)
 #pragma unroll

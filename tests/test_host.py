@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_load_binds_and_reports_version():
     lib = _lib.load()
-    assert lib.conv3p_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.conv3p_abi_version() == _lib.ABI_VERSION == 5
     assert _lib.status_string(0) == "ok"
     assert "workspace" in _lib.status_string(_lib.ERR_WORKSPACE)
     assert lib.conv3p_profile_kinds() >= 5
