@@ -657,6 +657,9 @@ def main():
     ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
                     help="cfg2 (default; cfg3 at --gpus 8): B=32 x N=2048 per GPU, 4-layer stack.  cfg5: B=16 x N=8192 per "
                          "GPU, one 128->256 layer, one 3.54 MB all-reduce")
+    ap.add_argument("--fused", choices=("forward", "backward"), default=None, help="developer: only that pass fused")
+    ap.add_argument("--no-fused", action="store_true", help="developer A/B: per-layer launches only (the default lets "
+                    "Conv3pStack.tune() fuse the forward pass's hidden layers into one launch for clouds with short pair lists)")
     ap.add_argument("--fused-stack", action="store_true",
                     help="developer: the hidden layers of a pass as ONE launch (CONV3P_CACHE_FUSED_STACK, opt-in; echoed "
                          "into config; the default run reports it beside the headline as fused_stack_ms_per_step)")
@@ -703,7 +706,7 @@ def main():
     tP, tX = tPs[0], tXs[0]
     ups = [torch.from_numpy(u).to(dev) for u in ups_np]
     gcat = torch.cat(ups, dim=2).contiguous()      # dL/dconcat (B, N, 36): what the model's dense head hands back
-    st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial, fused_launch=args.fused_stack)
+    st = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial, fused_launch=True if args.fused_stack else (args.fused or (False if args.no_fused else "auto")))
     counter = [0]
     # set-up, not a step: create the RCCL communicator (seconds on the first collective), allocate the stack's
     # neighbour caches and load the library's code object (one 64-point call) before anything is timed,
@@ -772,7 +775,7 @@ def main():
     kinds_iso = None
     if extra and prefetch:
         # the same steps with no side stream at all: kernels run alone, one after the other
-        st_iso = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=False)
+        st_iso = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=False, fused_launch=st.fused_launch)
         st_iso.sparse_neighbourhoods = st.sparse_neighbourhoods
         st_iso.prepare(B_PER_GPU, N_POINTS)
         step_iso = make_step(st_iso, False)
@@ -857,26 +860,26 @@ def main():
             out["config"]["hip_library_override"] = os.environ["CONV3P_HIP_LIB"]
         if os.environ.get("CONV3P_BENCH_PRESORT"):   # (the input order of the clouds is part of the workload: never silently)
             out["config"]["developer_presorted_clouds"] = "Morton order (CONV3P_BENCH_PRESORT): NOT the headline workload"
-        if args.fused_stack:
-            out["config"]["fused_stack_launches"] = "CONV3P_CACHE_FUSED_STACK: hidden layers of a pass as one launch (opt-in, --fused-stack)"
-            out["config"]["fused_status"] = list(st.fused_status())
+        out["config"]["fused_launches"] = {"auto": "none (tune() saw long pair lists)", False: "none (--no-fused)", True: "forward and backward (--fused-stack)",
+                                           "forward": "the forward pass's hidden layers as ONE launch (CONV3P_CACHE_FUSED_FORWARD, set by Conv3pStack.tune() for short pair lists)",
+                                           "backward": "backward only (--fused backward)"}[st.fused_launch]
+        out["config"]["fused_status"] = list(st.fused_status())
         if world > 1:
             out["rccl_world"] = rccl_world
             out["allreduce_ms_per_step"] = None if allreduce_ms is None else round(allreduce_ms, 4)
             out["allreduce_exposed_ms_per_step"] = None if allreduce_exposed_ms is None else round(allreduce_exposed_ms, 4)
             out["ms_per_step_ranks"] = spread
             out["allreduce_bytes"] = int(st.fused_grad.numel() * 4)
-        if extra and not args.fused_stack:
-            # the same step with the hidden layers of each pass as ONE launch (opt-in CONV3P_CACHE_FUSED_STACK): built in
-            # round 6, measured, not the default
-            st_f = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial, fused_launch=True)
-            st_f.sparse_neighbourhoods = st.sparse_neighbourhoods
-            st_f.prepare(B_PER_GPU, N_POINTS)
-            step_f = make_step(st_f, prefetch)
-            dt_f = timed(dev, step_f, min(args.steps, 30), 5)
-            out["fused_stack_ms_per_step"] = round(dt_f * 1e3, 4)
-            out["fused_stack_status"] = list(st_f.fused_status())
-            del st_f
+        if extra and not (args.fused_stack or args.fused or args.no_fused):
+            # the same step with per-layer launches only / with BOTH passes' hidden layers fused
+            for key, fl in (("per_layer_launches_ms_per_step", False), ("fused_both_passes_ms_per_step", True)):
+                st_f = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, overlap_search=not args.serial, fused_launch=fl)
+                st_f.sparse_neighbourhoods = st.sparse_neighbourhoods
+                st_f.prepare(B_PER_GPU, N_POINTS)
+                step_f = make_step(st_f, prefetch)
+                dt_f = timed(dev, step_f, min(args.steps, 30), 5)
+                out[key] = round(dt_f * 1e3, 4)
+                del st_f
         if extra:
             # the drop-in boundary as the TF shim drives it: stateless ops, SELU as separate ops
             st_plain = stack.Conv3pStack(C_IN, None, device=dev, seed=1234, use_cache=False)

@@ -155,12 +155,16 @@ typedef struct conv3p_cache_config {
 /* conv3p_stack_forward_* / conv3p_stack_backward_* only, OPT-IN: run the hidden layers of a pass as ONE launch with
  * per-cloud barriers between the layers (pointwise_amd/csrc/conv3p_stack_fused.hpp) where the stack, the cache and the
  * device allow it (fp32, in_channels 3 or 9, hidden 9, the whole grid resident at once; the backward also needs
- * CONV3P_CACHE_SPARSE_NEIGHBOURHOODS).  Same bits for the activations and grad_input as the per-layer launches; grad_filter
- * sums its partials in another order (tolerance of the op).  Measured (profiles/r06_ab_fused.txt, r06_cfg4_ab.txt): cfg2
- * 0.420 against 0.436 ms with nothing else on the GPU, 0.420 against 0.417 beside the next batch's search (the fused kernels
- * hold every slot of the chip while their tiles wait for the slowest tile of their cloud); the rooms of cfg4, whose tiles
- * differ far more, 1.36 against 1.26 ms.  Hence not the default. */
-#define CONV3P_CACHE_FUSED_STACK 16
+ * CONV3P_CACHE_SPARSE_NEIGHBOURHOODS).  One bit per pass.  Same bits for the activations and grad_input as the per-layer
+ * launches; grad_filter sums its partials in another order (tolerance of the op).  Measured (profiles/r06_ab_fused.txt,
+ * r06_cfg4_ab.txt): the fused FORWARD is 68 against 86 us on cfg2 and nothing runs beside the forward
+ * in a pipelined step, so it is a gain there; the fused BACKWARD holds every slot of the chip while its tiles wait for the
+ * slowest tile of their cloud, which keeps the next batch's search out (cfg2: no gain); on the rooms of cfg4, whose tiles
+ * differ far more, both lose (1.34 against 1.26 ms).  Hence opt-in; Conv3pStack.tune() sets the forward bit for clouds
+ * with short pair lists. */
+#define CONV3P_CACHE_FUSED_FORWARD 16
+#define CONV3P_CACHE_FUSED_BACKWARD 32
+#define CONV3P_CACHE_FUSED_STACK (CONV3P_CACHE_FUSED_FORWARD | CONV3P_CACHE_FUSED_BACKWARD)
 
 size_t conv3p_cache_bytes(int elem_bytes, int B, int N, const conv3p_cache_config *cfg);
 /* Drop the host-side bookkeeping of a cache buffer (call before freeing it). */

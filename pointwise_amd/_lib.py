@@ -23,7 +23,9 @@ CACHE_POINTS_UNCHANGED = 1
 CACHE_SPARSE_NEIGHBOURHOODS = 2   # tuning hints, see include/conv3p.h
 CACHE_DENSE_NEIGHBOURHOODS = 8
 CACHE_PREPARE_DEEP_ORDERS = 4     # conv3p_cache_prepare_*: also the matrix-core path's record orders
-CACHE_FUSED_STACK = 16            # conv3p_stack_*: hidden layers of a pass as ONE launch (opt-in, see include/conv3p.h)
+CACHE_FUSED_FORWARD = 16          # conv3p_stack_*: hidden layers of the forward / backward pass as ONE launch (opt-in, see
+CACHE_FUSED_BACKWARD = 32         # include/conv3p.h)
+CACHE_FUSED_STACK = CACHE_FUSED_FORWARD | CACHE_FUSED_BACKWARD
 ABI_VERSION = 5                # CONV3P_ABI_VERSION of include/conv3p.h
 STACK_MAX_LAYERS = 8
 

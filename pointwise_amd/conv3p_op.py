@@ -62,7 +62,8 @@ class NeighborCache:
         # kernel) must call forget_points() or leave this off.
         self.trust_tensor_identity = trust_tensor_identity
         self._held = None
-        self.fused_stack = fused_stack   # CONV3P_CACHE_FUSED_STACK for the stack-level entry points (opt-in)
+        # CONV3P_CACHE_FUSED_FORWARD / _BACKWARD for the stack-level entry points (opt-in): True = both, or "forward" / "backward"
+        self.fused_stack = fused_stack
         self.cfg = _lib.CacheConfig(slots, max_taps, pairs_per_point, max_cin, max_cout, 0)
         # None: the library decides on the device which backward kernel serves the dilated narrow layers; True / False:
         # CONV3P_CACHE_SPARSE_NEIGHBOURHOODS / CONV3P_CACHE_DENSE_NEIGHBOURHOODS (include/conv3p.h), saving an empty launch
@@ -82,7 +83,8 @@ class NeighborCache:
                          (0 if self.sparse_neighbourhoods is None else _lib.CACHE_SPARSE_NEIGHBOURHOODS
                           if self.sparse_neighbourhoods else _lib.CACHE_DENSE_NEIGHBOURHOODS) | \
                          (_lib.CACHE_PREPARE_DEEP_ORDERS if deep_orders else 0) | \
-                         (_lib.CACHE_FUSED_STACK if self.fused_stack else 0)
+                         (_lib.CACHE_FUSED_FORWARD if self.fused_stack in (True, "forward") else 0) | \
+                         (_lib.CACHE_FUSED_BACKWARD if self.fused_stack in (True, "backward") else 0)
         return ctypes.addressof(self.cfg)
 
     def _identity_hint(self, points):

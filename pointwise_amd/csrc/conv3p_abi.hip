@@ -2106,7 +2106,7 @@ bool stack_fusable(const conv3p_stack_desc *sd, T voxel, int B, int N, const con
     if constexpr (sizeof(T) != 4) {
         return false;
     } else {
-        if ((cfg->flags & CONV3P_CACHE_FUSED_STACK) == 0) return false;   // opt-in (include/conv3p.h: measured, not a win by default)
+        if ((cfg->flags & CONV3P_CACHE_FUSED_STACK) == 0) return false;   // opt-in, one bit per pass (include/conv3p.h; the callers test theirs)
         if (sd->hidden != 9 || (sd->in_channels != 3 && sd->in_channels != 9) || sd->n_hidden < 2 || sd->n_hidden > kStackMaxFused) return false;
         if (sd->fz * sd->fy * sd->fx > 32 || N <= kTile || N > kFusedMaxPoints) return false;
         if (scratch_cap_needed > scratch_cap) return false;
@@ -2141,7 +2141,8 @@ int stack_forward_fused(const conv3p_stack_desc *sd, const T *points, const T *i
         const size_t handoff = up(rows * H * sizeof(T));
         const Where wh0 = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
                                      cfg->max_Cin, cfg->max_Cout, 0);
-        if (!stack_fusable<T>(sd, voxel, B, N, cfg, handoff * (size_t)(nh - 1), wh0.scratch_cap)) return CONV3P_ERR_UNSUPPORTED;
+        if ((cfg->flags & CONV3P_CACHE_FUSED_FORWARD) == 0 || !stack_fusable<T>(sd, voxel, B, N, cfg, handoff * (size_t)(nh - 1), wh0.scratch_cap))
+            return CONV3P_ERR_UNSUPPORTED;
         const FusedDevice &fd = fused_device();
         const int ntiles = (N + kTile - 1) / kTile;
         Dims d0{B, N, sd->in_channels, H, sd->fz, sd->fy, sd->fx, sd->fz * sd->fy * sd->fx, ntiles};
@@ -2248,7 +2249,8 @@ int stack_forward_impl(const conv3p_stack_desc *sd, const T *points, const T *in
     {
         const Where wh0 = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
                                      cfg->max_Cin, cfg->max_Cout, 0);
-        if (stack_fusable<T>(sd, voxel, B, N, cfg, up((size_t)B * N * sd->hidden * sizeof(T)) * (size_t)(sd->n_hidden - 1), wh0.scratch_cap)) {
+        if ((cfg->flags & CONV3P_CACHE_FUSED_FORWARD) != 0 &&
+            stack_fusable<T>(sd, voxel, B, N, cfg, up((size_t)B * N * sd->hidden * sizeof(T)) * (size_t)(sd->n_hidden - 1), wh0.scratch_cap)) {
             if (events && !prefetched && hipStreamWaitEvent(main, ev[sd->n_hidden - 1], 0) != hipSuccess) return CONV3P_ERR_LAUNCH;
             const int rc = stack_forward_fused<T>(sd, points, input, filters, voxel, B, N, concat, cache, cache_bytes, cfg, main, events);
             if (rc == CONV3P_OK) first = sd->n_hidden;
@@ -2311,7 +2313,7 @@ int stack_backward_fused(const conv3p_stack_desc *sd, const T *points, const T *
         return CONV3P_ERR_UNSUPPORTED;
     } else {
         const int nh = sd->n_hidden, H = sd->hidden, CW = nh * H;
-        if ((cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS) == 0) return CONV3P_ERR_UNSUPPORTED;
+        if ((cfg->flags & CONV3P_CACHE_SPARSE_NEIGHBOURHOODS) == 0 || (cfg->flags & CONV3P_CACHE_FUSED_BACKWARD) == 0) return CONV3P_ERR_UNSUPPORTED;
         const Where wh0 = persistent((int)sizeof(T), B, N, cache, cache_bytes, cfg->slots, cfg->max_taps, cfg->pairs_per_point,
                                      cfg->max_Cin, cfg->max_Cout, 0);
         if (!stack_fusable<T>(sd, voxel, B, N, cfg, 0, wh0.scratch_cap)) return CONV3P_ERR_UNSUPPORTED;

@@ -34,7 +34,7 @@ def _side_stream(device):
 
 class Conv3pStack:
     def __init__(self, in_channels, num_class=None, device="cuda:0", dtype=torch.float32, seed=1234,
-                 use_cache=True, overlap_search=True, fuse_selu=True, c_stack=True, fused_launch=False):
+                 use_cache=True, overlap_search=True, fuse_selu=True, c_stack=True, fused_launch="auto"):
         """num_class=None: classification stack (4 layers); an int: segmentation stack (5 layers).
         use_cache: keep the geometry (sorted points, populations, neighbour lists) of each layer's stencil in
         a NeighborCache so that the search runs once per (points, stride) instead of once per op call.
@@ -43,8 +43,11 @@ class Conv3pStack:
         buffer.  Needs use_cache and fuse_selu; shapes outside the register-resident list fall back to the op-by-op
         composition below (same results)."""
         self.use_cache = use_cache
-        # fused_launch (opt-in, needs c_stack): the hidden layers of a pass as ONE launch with per-cloud barriers
-        # (CONV3P_CACHE_FUSED_STACK, csrc/conv3p_stack_fused.hpp); measured: not a win by default (include/conv3p.h)
+        # fused_launch (needs c_stack): the hidden layers of a pass as ONE launch with per-cloud barriers
+        # (CONV3P_CACHE_FUSED_FORWARD / _BACKWARD, csrc/conv3p_stack_fused.hpp).  True = both passes, "forward" / "backward",
+        # False = never; "auto" (default) = nothing until tune() has seen the data, then the FORWARD pass for clouds with short
+        # pair lists (measured: cfg2 0.405 against 0.420 ms; the fused backward keeps the next batch's search out, and on the
+        # rooms of cfg4, whose tiles differ far more, both passes lose -- include/conv3p.h, DESIGN.md section 5e)
         self.fused_launch = fused_launch
         # None: the backward kernel of the dilated layers is chosen on the device from the lists themselves; True / False:
         # the CONV3P_CACHE_SPARSE / DENSE_NEIGHBOURHOODS hint for the stack's caches, set by tune() (or by hand before the
@@ -100,6 +103,9 @@ class Conv3pStack:
         for li, (_, _, s) in enumerate(self.layers):
             for a in range(3):
                 self._desc.strides[li][a] = s
+
+    def _fused_flag(self):
+        return False if self.fused_launch == "auto" else self.fused_launch
 
     def fused_status(self):
         """(forward launches, backward launches, error bits) summed over the stack's caches: how many passes ran as ONE
@@ -253,7 +259,7 @@ class Conv3pStack:
                 self._pending.pop(idx, None)
             c = op.NeighborCache(B, N, points.dtype, points.device, slots=len(self.layers), max_taps=27,
                                  max_cin=cmax, max_cout=cmax, sparse_neighbourhoods=self.sparse_neighbourhoods,
-                                 fused_stack=self.fused_launch)
+                                 fused_stack=self._fused_flag())
             self._caches[idx] = c
         return c
 
@@ -271,9 +277,12 @@ class Conv3pStack:
         sample = points[: min(points.shape[0], 8)].contiguous()
         mean = max(float(op.neighbor_count(sample, (3, 3, 3), (s, s, s), VOXEL).sum(dim=2).float().mean()) for s in strides)
         self.sparse_neighbourhoods = bool(mean <= threshold)
+        if self.fused_launch == "auto" and self.sparse_neighbourhoods and self.c_stack:
+            self.fused_launch = "forward"   # short lists, even tiles: the forward's hidden layers as one launch
         for c in self._caches:
             if c is not None:
                 c.sparse_neighbourhoods = self.sparse_neighbourhoods
+                c.fused_stack = self._fused_flag()
         return self.sparse_neighbourhoods
 
     def prepare(self, B, N):
@@ -286,7 +295,7 @@ class Conv3pStack:
                     self._caches[idx] = op.NeighborCache(B, N, self.dtype, self.device, slots=len(self.layers),
                                                          max_taps=27, max_cin=cmax, max_cout=cmax,
                                                          sparse_neighbourhoods=self.sparse_neighbourhoods,
-                                                         fused_stack=self.fused_launch)
+                                                         fused_stack=self._fused_flag())
 
     def _cache_for(self, points):
         if not self.use_cache:
