@@ -1003,12 +1003,22 @@ __device__ __forceinline__ void forward_tile(
     // (fused stack launch: the neighbour rows are another tile's output of the previous layer -- everything above and the
     // records are requested first, the rows once the cloud's tiles have all arrived)
     if (kSmall && !overflow) start_group(0, !Sync::kActive);
+    // (fused stack launch: the table of reciprocals needs nothing of the previous layer either -- written before the wait, the
+    // one workgroup barrier after the wait publishes it: no division and no second barrier between the wait and the loop)
+    const bool early_table = Sync::kActive && kSmall && !overflow && tc_fits;   // (uniform)
+    if (early_table) {
+#pragma unroll
+        for (int u = 0; u < kTcPer; ++u) {
+            const int e = (int)tid + 256 * u;
+            if (e < st.ntap * kTile) rcpt[(e >> 6) * kCntStride + (e & 63)] = (T)1 / (T)tcv[u];
+        }
+    }
     sync.wait();
     FDBG()
     __syncthreads();
     FDBG()
     if (Sync::kActive && kSmall && !overflow) start_rows();
-    {
+    if (!early_table) {
         // own populations -> LDS [tap][centre]; the dense small path keeps 1 / (T)count instead (the IEEE quotient,
         // .cpp:483: one division per (centre, tap) here rather than one per pair)
         const bool as_rcp = kSmall && !overflow;
