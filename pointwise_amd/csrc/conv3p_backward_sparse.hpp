@@ -37,9 +37,6 @@
 #ifndef CONV3P_SP_FUSE_BC
 #define CONV3P_SP_FUSE_BC 0   // developer A/B: 1 = phases B and C of a one-round tile interleaved tap by tap (9 -> 9 at the cfg2 size: 45.1 us against 45.8, but 2 spilled registers at the 128-register cap: not shipped)
 #endif
-#ifndef CONV3P_SP_ABLATE
-#define CONV3P_SP_ABLATE 0   // developer ablation switch (tools/ablate_sparse.sh); 0 in every shipped build
-#endif
 
 namespace conv3p {
 
@@ -116,13 +113,7 @@ __device__ __forceinline__ void backward_sparse_tile(
     uint32_t sub = lane & 3u, maxn = 4u;
     uint32_t *share = reinterpret_cast<uint32_t *>(soa);   // the wave's lane-sharing scratch (soa is the overflow path's)
 
-#if CONV3P_SP_ABLATE & 128
-    long long st_[10];
-    int sti_ = 0;
-#define SDBG() { __builtin_amdgcn_s_waitcnt(0); st_[sti_++] = wall_clock64(); }
-#else
-#define SDBG()
-#endif
+    DEV_SP_DECL()
     SDBG()
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
@@ -754,14 +745,7 @@ __device__ __forceinline__ void backward_sparse_tile(
         if constexpr (kHalves) {
             f32x4 accR[4][NKC];
             zero_acc(accR);
-#if CONV3P_SP_ABLATE & 128
-            long long ra_ = 0, rb_ = 0, rc_ = 0, rs_ = 0, t_;
-            int nrs_ = 0;
-#define HDBG(v) { __builtin_amdgcn_s_waitcnt(0); const long long n_ = wall_clock64(); v += n_ - t_; t_ = n_; }
-            __builtin_amdgcn_s_waitcnt(0); t_ = wall_clock64();
-#else
-#define HDBG(v)
-#endif
+            DEV_SP_ROUNDS_DECL()
             for (int h = 0; h < 2; ++h) {
                 __syncthreads();   // the row bookkeeping and G of the previous half (of the whole tile) are no longer read
                 mybm = (lane >> 5) == h ? mybm_all : (BM)0;
@@ -773,25 +757,19 @@ __device__ __forceinline__ void backward_sparse_tile(
                     if (r > 0) __syncthreads();
                     zero_G(t1);
                     __syncthreads();
-                    HDBG(rs_)
+                    DEV_SP_ACC(rs_)
                     phase_A_wide(h, t0, t1);
-                    HDBG(ra_)
+                    DEV_SP_ACC(ra_)
                     __syncthreads();
-                    HDBG(rs_)
+                    DEV_SP_ACC(rs_)
                     phase_B(t0, t1, h > 0);
-                    HDBG(rb_)
+                    DEV_SP_ACC(rb_)
                     phase_C_mfma(t0, t1, accR, h);
-                    HDBG(rc_)
-#if CONV3P_SP_ABLATE & 128
-                    ++nrs_;
-#endif
+                    DEV_SP_ACC(rc_)
+                    DEV_SP_ROUND()
                 }
             }
-#if CONV3P_SP_ABLATE & 128
-            if (lane == 0 && (blockIdx.x % 211) == 7)
-                printf("bsp<%d,%d> wg %d wave %d: rounds %d  prologue %lld  syncs %lld  phaseA %lld  B %lld  C %lld\n", CIN, COUT, (int)blockIdx.x, wave,
-                       nrs_, st_[1] - st_[0], rs_, ra_, rb_, rc_);
-#endif
+            DEV_SP_ROUNDS_PRINT(CIN, COUT, wave, lane, nrs_)
             __syncthreads();   // red aliases G: every wave is done with its last phase C
             red_from_acc(accR);
             red_written = true;
@@ -801,39 +779,29 @@ __device__ __forceinline__ void backward_sparse_tile(
         for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
         f32x4 accR[kMfmaCRounds ? 4 : 1][kMfmaCRounds ? NKC : 1];
         if constexpr (kMfmaCRounds) zero_acc(accR);
-#if CONV3P_SP_ABLATE & 128
-        long long ra_ = 0, rb_ = 0, rc_ = 0, rs_ = 0, t_;
-#define RDBG(v) { __builtin_amdgcn_s_waitcnt(0); const long long n_ = wall_clock64(); v += n_ - t_; t_ = n_; }
-        __builtin_amdgcn_s_waitcnt(0); t_ = wall_clock64();
-#else
-#define RDBG(v)
-#endif
+        DEV_SP_ROUNDS_DECL()
         for (int r = 0; r < nrounds; ++r) {
             const int t0 = (int)rinfo[1 + r], t1 = (int)rinfo[2 + r];
             if (r > 0) __syncthreads();   // the previous round's phases B / C are done with G
             zero_G(t1);
             __syncthreads();
-            RDBG(rs_)
+            DEV_SP_ACC(rs_)
             phase_A(t0, t1);
-            RDBG(ra_)
+            DEV_SP_ACC(ra_)
             __syncthreads();
-            RDBG(rs_)
+            DEV_SP_ACC(rs_)
             phase_B(t0, t1);
-            RDBG(rb_)
+            DEV_SP_ACC(rb_)
             if constexpr (kMfmaCRounds) phase_C_mfma(t0, t1, accR);
             else phase_C(t0, t1, dx);
-            RDBG(rc_)
+            DEV_SP_ACC(rc_)
         }
         if constexpr (kMfmaCRounds) {
             __syncthreads();   // red aliases G: every wave is done with its last phase C
             red_from_acc(accR);
             red_written = true;
         }
-#if CONV3P_SP_ABLATE & 128
-        if (lane == 0 && (blockIdx.x % 211) == 7)
-            printf("bsp<%d,%d> wg %d wave %d: rounds %d  prologue %lld  syncs %lld  phaseA %lld  B %lld  C %lld\n", CIN, COUT, (int)blockIdx.x, wave,
-                   nrounds, st_[1] - st_[0], rs_, ra_, rb_, rc_);
-#endif
+        DEV_SP_ROUNDS_PRINT(CIN, COUT, wave, lane, nrounds)
     }
     // ---- grad_input rows: fixed-order sum of the four waves' partial rows
     if (!red_written) {
@@ -854,12 +822,7 @@ __device__ __forceinline__ void backward_sparse_tile(
             grad_input[rr * ld.dx + k] = sum;
         }
     }
-#if CONV3P_SP_ABLATE & 128
-    SDBG()
-    if (lane == 0 && nrounds == 1 && (blockIdx.x % 211) == 7)   // developer instrumentation build only (10 ns ticks)
-        printf("bsp<%d,%d> wg %d wave %d: prologue %lld  zero+sync %lld  phaseA %lld  sync %lld  B %lld  C %lld  reduce+store %lld\n", CIN, COUT,
-               (int)blockIdx.x, wave, st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4], st_[6] - st_[5], st_[7] - st_[6]);
-#endif
+    DEV_SP_PRINT(CIN, COUT, wave, lane, nrounds == 1)
     sync.arrive();
 }
 

@@ -25,12 +25,10 @@
 //   C/D: register r of lane l is C[row = (r & 3) + 8*(r >> 2) + 4*(l >> 5)][col = l & 31].
 #pragma once
 
+#include "conv3p_dev.hpp"
 #include "conv3p_device.hpp"
 #include <type_traits>
 
-#ifndef CONV3P_ABLATE
-#define CONV3P_ABLATE 0
-#endif
 #ifndef DEEP_GEMM_WAVES
 #define DEEP_GEMM_WAVES 2
 #endif
@@ -512,14 +510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
             }
         }
     }
-#if CONV3P_ABLATE & 16777216
-    long long gk[6] = {0, 0, 0, 0, 0, 0};
-    long long gstart = wall_clock64();
-#define GDBG(i) { const long long t_ = wall_clock64(); gk[i] += t_ - glast; glast = t_; }
-    long long glast = wall_clock64();
-#else
-#define GDBG(i)
-#endif
+    DEV_GEMM_DECL()
     // populated taps, longest run first (ties: lower tap): position = number of taps ahead (wave 0, lane = tap)
     if (wave == 0) {
         const uint32_t len = lane < ntap ? toff[lane + 1] - toff[lane] : 0u;
@@ -780,11 +771,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEEP_GEMM_W
     }
 
     GDBG(5)
-#if CONV3P_ABLATE & 16777216
-    if (lane == 0 && (blockIdx.x % 400) == 100)   // developer instrumentation build only
-        printf("gemm<%d,%d,%d> wg %d wave %d dbg (10 ns ticks): total %lld | stage 1 (+ barriers) %lld  gbuf + stage 2 %lld  tail %lld | taps %d\n",
-               KDIM, NDIM, (int)BWD, (int)blockIdx.x, wave, wall_clock64() - gstart, gk[0], gk[4], gk[5], nne);
-#endif
+    DEV_GEMM_PRINT(KDIM, NDIM, BWD, wave, lane, nne)
     // ---- epilogue: C fragments -> out rows (by original index)
     // non-finite rows of `src` (or a sum that overflowed) have made some accumulator non-finite: x - x is 0 only for
     // finite x

@@ -8,12 +8,10 @@
 //   selu kernels           the activation between the stack's layers (selu.py:22-26)
 #pragma once
 
+#include "conv3p_dev.hpp"      // developer instruments (ablation switches, per-phase stamps): nothing in product builds
 #include "conv3p_device.hpp"
 #include "conv3p_deep.hpp"
 
-#ifndef CONV3P_ABLATE
-#define CONV3P_ABLATE 0   // developer ablation switch (tools/ablate.sh); 0 in every shipped build
-#endif
 #ifndef CONV3P_BWD_MFMA
 #define CONV3P_BWD_MFMA 1   // backward phases B and C on the matrix cores (fp32); 0: the vector-ALU version (A/B builds)
 #endif
@@ -914,13 +912,7 @@ __device__ __forceinline__ void forward_tile(
     uint32_t sub = lane & 3u, nsub = 4u;   //   ... its index among the centre's lanes, and their number
     uint32_t *share = reinterpret_cast<uint32_t *>(soa);   // the wave's lane-sharing scratch (soa is the overflow path's)
 
-#if CONV3P_ABLATE & 134217728
-    long long ft[8];
-    int fti = 0, fsteps = 0;
-#define FDBG() { __builtin_amdgcn_s_waitcnt(0); ft[fti++] = wall_clock64(); }
-#else
-#define FDBG()
-#endif
+    DEV_FWD_DECL()
     FDBG()
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     // the tile's populations (tile-major copy): issued before the filter so that both are in flight together
@@ -1140,9 +1132,7 @@ __device__ __forceinline__ void forward_tile(
                             }
                         }
                         i += nsub;
-#if CONV3P_ABLATE & 134217728
-                        fsteps++;
-#endif
+                        DEV_FWD_STEP()
                     }
                 }
                 FDBG()
@@ -1192,12 +1182,7 @@ __device__ __forceinline__ void forward_tile(
                     if (out2 != nullptr) out2[((size_t)b * N + orig) * ld_out2 + ch] = r;
                 }
             }
-#if CONV3P_ABLATE & 134217728
-            FDBG()
-            if (lane == 0 && (blockIdx.x % 211) == 7)   // developer instrumentation build only (10 ns ticks)
-                printf("fwd<%d,%d> wg %d wave %d: loads %lld sync %lld table %lld qsegs %lld first-recs %lld loop %lld (%d steps) epilogue %lld\n", CIN, COUT,
-                       (int)blockIdx.x, wave, ft[1] - ft[0], ft[2] - ft[1], ft[3] - ft[2], ft[4] - ft[3], ft[5] - ft[4], ft[6] - ft[5], fsteps, ft[7] - ft[6]);
-#endif
+            DEV_FWD_PRINT(CIN, COUT, wave, lane)
         } else {
             // overflow path ran lane = centre in every wave: fixed-order sum of the per-wave partial rows
 #pragma unroll
@@ -1297,13 +1282,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
     int cq = wave * 16 + (lane >> 2);      // dense phase A: this lane's centre (re-dealt there, share_lanes), ...
     uint32_t sub = lane & 3u, maxn = 4u;   //   its index among the centre's lanes, the largest lane count of a centre
 
-#if CONV3P_ABLATE & 33554432
-    long long bt[8];
-    int bti = 0;
-#define BDBG() { __builtin_amdgcn_s_waitcnt(0); bt[bti++] = wall_clock64(); }
-#else
-#define BDBG()
-#endif
+    DEV_BWD_DECL()
     BDBG()
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     if constexpr (kSmall) {
@@ -1719,12 +1698,7 @@ __global__ __launch_bounds__(256) void backward_kernel(
                     }
                 }
         }
-#if CONV3P_ABLATE & 33554432
-        BDBG()
-        if (lane == 0 && (blockIdx.x % 211) == 7)   // developer instrumentation build only (10 ns ticks)
-            printf("bwd<%d,%d> wg %d wave %d: prologue %lld  phaseA %lld  sync %lld  B %lld  C %lld  reduce+store %lld\n", CIN, COUT,
-                   (int)blockIdx.x, wave, bt[1] - bt[0], bt[2] - bt[1], bt[3] - bt[2], bt[4] - bt[3], bt[5] - bt[4], bt[6] - bt[5]);
-#endif
+        DEV_BWD_PRINT(CIN, COUT, wave, lane)
     }
 }
 
