@@ -161,7 +161,10 @@ typedef struct conv3p_cache_config {
  * in a pipelined step, so it is a gain there; the fused BACKWARD holds every slot of the chip while its tiles wait for the
  * slowest tile of their cloud, which keeps the next batch's search out (cfg2: no gain); on the rooms of cfg4, whose tiles
  * differ far more, both lose (1.34 against 1.26 ms).  Hence opt-in; Conv3pStack.tune() sets the forward bit for clouds
- * with short pair lists. */
+ * with short pair lists.  ONE fused launch at a time per device: a waiting tile needs the rest of its cloud resident or
+ * dispatchable, and two fused launches issued concurrently (two streams, two processes on one GPU) can hold the slots each
+ * other's tiles wait for; every wait is bounded (half a second), a wait that gives up is reported through
+ * conv3p_cache_fused_status AND fails the next stack call on that cache with CONV3P_ERR_LAUNCH. */
 #define CONV3P_CACHE_FUSED_FORWARD 16
 #define CONV3P_CACHE_FUSED_BACKWARD 32
 #define CONV3P_CACHE_FUSED_STACK (CONV3P_CACHE_FUSED_FORWARD | CONV3P_CACHE_FUSED_BACKWARD)

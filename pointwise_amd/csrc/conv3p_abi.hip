@@ -1353,6 +1353,7 @@ struct CacheHost {
     int sync_clouds = 0;
     uint32_t sync_base[2] = {0u, 0u};
     uint32_t fused_launches[2] = {0u, 0u};
+    uint32_t *host_err = nullptr;      // one word of host-mapped memory the fused kernels set on an error (looked at before every launch)
 };
 std::mutex g_cache_mu;
 std::map<void *, CacheHost> g_caches;
@@ -1414,12 +1415,13 @@ int begin_call(Call<T> &c, const Dims &d, const int32_t *stride, T voxel, size_t
         std::vector<hipEvent_t> keep;
         keep.swap(h.ready);            // the stack-level entry points' events outlive a re-shape of the cache
         uint32_t *const ksync = h.sync;   // ... and so do the fused launches' counters
+        uint32_t *const kherr = h.host_err;
         const int kclouds = h.sync_clouds;
         const uint32_t kb0 = h.sync_base[0], kb1 = h.sync_base[1], kf0 = h.fused_launches[0], kf1 = h.fused_launches[1];
         h = CacheHost();
         h.ready.swap(keep);
         h.sync = ksync; h.sync_clouds = kclouds; h.sync_base[0] = kb0; h.sync_base[1] = kb1;
-        h.fused_launches[0] = kf0; h.fused_launches[1] = kf1;
+        h.fused_launches[0] = kf0; h.fused_launches[1] = kf1; h.host_err = kherr;
         h.B = d.B; h.N = d.N; h.elem = (int)sizeof(T); h.ntap_max = ntap_max; h.nslots = wh.nslots; h.ppp = wh.ppp;
         h.tags.assign(wh.nslots, 0ull);
         h.stamp.assign(wh.nslots, 0ull);
@@ -2066,17 +2068,41 @@ int fused_capacity(const void *kern, size_t lds, int cus)
 }
 // the cache's arrival counters (created at the first fused launch on it; zero-filled once, never reset: the host tracks
 // their value)
-uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &base)
+uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &base, int *status)
 {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     CacheHost &h = g_caches[cache];
+    *status = CONV3P_ERR_LAUNCH;
+    // an earlier fused launch on this cache reported an error (a barrier wait that gave up: e.g. two fused launches on one
+    // device at the same time, each holding the slots the other's tiles wait for; or a cloud whose tiles did not share an
+    // XCC): its results were wrong -- fail loudly now, once
+    if (h.host_err != nullptr && *reinterpret_cast<volatile uint32_t *>(h.host_err) != 0u) {
+        *reinterpret_cast<volatile uint32_t *>(h.host_err) = 0u;
+        return nullptr;
+    }
     if (h.sync != nullptr && h.sync_clouds < B) {
         (void)hipFree(h.sync);   // (synchronises: nothing can still be using it)
         h.sync = nullptr;
     }
     if (h.sync == nullptr) {
         const size_t words = (size_t)2 * B * kSyncLineWords;
-        if (hipMalloc(&h.sync, words * sizeof(uint32_t)) != hipSuccess || hipMemset(h.sync, 0, words * sizeof(uint32_t)) != hipSuccess) {
+        if (h.host_err == nullptr) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&h.host_err), sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) {
+                (void)hipGetLastError();
+                h.host_err = nullptr;
+                return nullptr;
+            }
+            *h.host_err = 0u;
+        }
+        void *dev_err = nullptr;
+        std::vector<uint32_t> init(words, 0u);
+        if (hipHostGetDevicePointer(&dev_err, h.host_err, 0) != hipSuccess) dev_err = nullptr;
+        for (size_t l = 0; l < words; l += kSyncLineWords) {   // words 4-5 of every line: where an error is also reported
+            init[l + 4] = (uint32_t)(reinterpret_cast<uintptr_t>(dev_err) & 0xFFFFFFFFu);
+            init[l + 5] = (uint32_t)((unsigned long long)reinterpret_cast<uintptr_t>(dev_err) >> 32);
+        }
+        if (hipMalloc(&h.sync, words * sizeof(uint32_t)) != hipSuccess ||
+            hipMemcpy(h.sync, init.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipGetLastError();
             h.sync = nullptr;
             return nullptr;
@@ -2087,6 +2113,7 @@ uint32_t *fused_sync(void *cache, int B, int kind, uint32_t arrivals, uint32_t &
     base = h.sync_base[kind];
     h.sync_base[kind] += arrivals;
     h.fused_launches[kind] += 1u;
+    *status = CONV3P_OK;
     return h.sync + (size_t)kind * h.sync_clouds * kSyncLineWords;
 }
 
@@ -2189,8 +2216,9 @@ int stack_forward_fused(const conv3p_stack_desc *sd, const T *points, const T *i
             }
         }
         a.N = N; a.ntiles = ntiles; a.nl = nh; a.bm = bm;
-        a.sync = fused_sync(cache, B, 0, (uint32_t)(ntiles * (nh - 1)), a.base);
-        if (a.sync == nullptr) return CONV3P_ERR_LAUNCH;
+        int srcs = CONV3P_OK;
+        a.sync = fused_sync(cache, B, 0, (uint32_t)(ntiles * (nh - 1)), a.base, &srcs);
+        if (a.sync == nullptr) return srcs;
         Scope sc(K_FORWARD, s);
         if (sd->in_channels == 3) hipLaunchKernelGGL((stack_forward_kernel<T, 3, 9>), dim3(grid_of(bm)), dim3(256), lds, s, a);
         else hipLaunchKernelGGL((stack_forward_kernel<T, 9, 9>), dim3(grid_of(bm)), dim3(256), lds, s, a);
@@ -2366,8 +2394,9 @@ int stack_backward_fused(const conv3p_stack_desc *sd, const T *points, const T *
         a.top_g = G[nh - 1];
         a.ld_act = CW;
         a.ld_ext = ld_ext;
-        a.sync = fused_sync(cache, B, 1, (uint32_t)(ntiles * k), a.base);
-        if (a.sync == nullptr) return CONV3P_ERR_LAUNCH;
+        int srcs = CONV3P_OK;
+        a.sync = fused_sync(cache, B, 1, (uint32_t)(ntiles * k), a.base, &srcs);
+        if (a.sync == nullptr) return srcs;
         Scope sc(K_BACKWARD, s);
         (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((stack_backward_kernel<T, 9>), dim3(grid_of(bm)), dim3(256), lds, s, a);
@@ -2512,6 +2541,7 @@ int conv3p_cache_forget(void *cache)
     if (it != g_caches.end()) {
         for (hipEvent_t e : it->second.ready) (void)hipEventDestroy(e);
         if (it->second.sync != nullptr) (void)hipFree(it->second.sync);
+        if (it->second.host_err != nullptr) (void)hipHostFree(it->second.host_err);
         g_caches.erase(it);
     }
     return CONV3P_OK;

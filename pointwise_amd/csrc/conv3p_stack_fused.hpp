@@ -56,6 +56,16 @@ __device__ __forceinline__ void l2_atomic_add(uint32_t *p, uint32_t v)
 }
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u; }   // HW_REG_XCC_ID[3:0]
 
+// An error of a fused launch (a wait gave up, a cloud's tiles on different XCCs): the bit goes to word 2 of the cloud's line
+// (conv3p_cache_fused_status) AND to a word of host-mapped memory whose address the host left in words 4-5 of every line --
+// the host looks at that word before the next fused launch on the cache and fails it loudly (CONV3P_ERR_LAUNCH).
+__device__ __forceinline__ void report_error(uint32_t *line, uint32_t bit)
+{
+    __hip_atomic_fetch_or(line + 2, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t *host_word = reinterpret_cast<uint32_t *>(((unsigned long long)line[5] << 32) | line[4]);
+    if (host_word != nullptr) __hip_atomic_fetch_or(host_word, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct CloudSync {
     static constexpr bool kActive = true;
     uint32_t *cnt;       // the cloud's line: [0] arrival counter (monotonic; the host tracks its value between launches),
@@ -68,7 +78,7 @@ struct CloudSync {
             int spins = 0;
             while ((int32_t)(l2_atomic_add_ret(cnt, 0u) - target) < 0) {
                 if (++spins >= kSyncMaxSpins) {
-                    __hip_atomic_fetch_or(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    report_error(cnt, 1u);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(CONV3P_SYNC_SLEEP);
@@ -120,8 +130,7 @@ __device__ __forceinline__ void publish_placement(uint32_t *line, uint32_t tag, 
 }
 __device__ __forceinline__ void check_placement(uint32_t *line, uint32_t tag, int qt)
 {
-    if (qt != 0 && threadIdx.x == 0 && l2_atomic_add_ret(line + 1, 0u) != ((tag << 4) | xcc_id()))
-        __hip_atomic_fetch_or(line + 2, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (qt != 0 && threadIdx.x == 0 && l2_atomic_add_ret(line + 1, 0u) != ((tag << 4) | xcc_id())) report_error(line, 2u);
 }
 
 // hidden layers 0 .. nl-1 of the stack; layer 0 has CIN0 inputs, the others H

@@ -1041,6 +1041,43 @@ def test_fused_stack_launch_equals_the_per_layer_launches(dev, cin, ncls, B, N, 
         assert rel_err(res[0][2].cpu().numpy(), ref_fused) <= 5e-5
 
 
+def test_fused_stack_launch_with_overflowed_pair_buffers(dev):
+    """Caches too small for the pair lists (pairs_per_point = 6: most tiles overflow and search themselves inside the
+    kernels): the fused launches take the same fallback inside their tile passes -- equal to the per-layer launches and to
+    the oracle."""
+    B, N, cin = 5, 900, 3
+    P = synth.modelnet_like(B, N, seed=15)
+    X = synth.features(B, N, cin, 16, points=P)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tp, tx = t(P), t(X)
+    ups = [synth.upstream_grad(B, N, stack.HIDDEN, 170 + i) for i in range(4)]
+    res = []
+    for fused in (True, False):
+        st = stack.Conv3pStack(cin, None, device=dev, seed=3, fused_launch=fused)
+        st.sparse_neighbourhoods = True
+        for i in (0, 1):
+            st._caches[i] = op.NeighborCache(B, N, torch.float32, dev, slots=len(st.layers), max_taps=27, max_cin=9, max_cout=9,
+                                             pairs_per_point=6, sparse_neighbourhoods=True, fused_stack=fused)
+        acts = st.forward(tp, tx)
+        dx, fg = st.backward([t(u) for u in ups])
+        f, b, e = st.fused_status()
+        assert e == 0 and (f, b) == ((1, 1) if fused else (0, 0))
+        res.append(([a.clone() for a in acts], dx.clone(), fg.clone()))
+    # (WHICH tiles overflow is decided by the order in which the tiles of a cloud reserve their slots -- a race between
+    # workgroups: two independently built caches need not agree, and an overflowed tile sums in another order -- so the two
+    # runs are compared within rounding, not bit for bit)
+    for a, r in zip(res[0][0], res[1][0]):
+        assert rel_err(a.cpu().numpy(), r.cpu().numpy()) <= 2e-6
+    assert rel_err(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) <= 2e-6
+    assert rel_err(res[0][2].cpu().numpy(), res[1][2].cpu().numpy()) <= 2e-6
+    st = stack.Conv3pStack(cin, None, device=dev, seed=3)
+    ref_acts, ref_dx, ref_fused = _oracle_stack(P, X, [f.cpu().numpy() for f in st.filters], st.layers, ups, None)
+    for a, r in zip(res[0][0], ref_acts):
+        assert rel_err(a.cpu().numpy(), r) <= 2e-5
+    assert rel_err(res[0][1].cpu().numpy(), ref_dx) <= 5e-5
+    assert rel_err(res[0][2].cpu().numpy(), ref_fused) <= 5e-5
+
+
 def test_cache_prepare_multi_equals_per_stencil_prepare(dev):
     """One batched search launch for strides 1..4 gives the same lists (hence bitwise the same op results) as
     four separate prepares; a second multi call on unchanged points launches nothing new and stays valid."""
