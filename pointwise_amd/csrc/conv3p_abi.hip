@@ -243,7 +243,7 @@ Layout<T> carve(int B, int N, int ntiles, int ntap_max, int nslots, int pairs_pe
         S.tcount = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)B * ntiles * kTile * ntap_max));
         S.segs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups));
         S.qsegs = reinterpret_cast<uint2 *>(take(sizeof(uint2) * (size_t)B * ntiles * L.ngroups * 64));
-        S.qbm = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * ntiles * 64 * (ntap_max > 32 ? 2 : 1)));
+        S.qbm = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * (size_t)B * ntiles * 64 * (ntap_max > 64 ? 4 : ntap_max > 32 ? 2 : 1)));   // one plane per 32 taps (up to 128)
         S.qbm_hi = ntap_max > 32 && S.qbm != nullptr ? S.qbm + (size_t)B * ntiles * 64 : nullptr;
         S.sched = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t) * 8 * (size_t)((B + 7) / 8) * ntiles));
         S.regime = reinterpret_cast<uint32_t *>(take(sizeof(uint32_t)));
@@ -473,10 +473,10 @@ template <typename T> int run_prep(const T *points, const Call<T> &c)
 
 template <typename T> size_t search_lds_bytes(const Stencil<T> &st, int gtiles)
 {
-    // (+ 512: search_tile's static array of the centres' backward-tap sets -- it counts against the 160 KiB like the dynamic part)
+    // (+ 1024: search_tile's static array of the centres' backward-tap sets -- it counts against the 160 KiB like the dynamic part)
     return lds_common(st) + a16((size_t)st.ntap * kCntStride * 4) + a16(sizeof(CentreRec<T>) * 64) + 64 * 3 * 4 +
            a16((size_t)gtiles * 64 * 8) + a16((size_t)gtiles * 4) + 32 + kWavesPerBlock * 64 * 4 +
-           a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4) + 512;
+           a16((size_t)kWavesPerBlock * 192 * 4) + a16((size_t)kWavesPerBlock * 256 * 4) + 1024;
 }
 
 // grid origin of every cloud, for stencils whose candidate window can decide (even dilated extents)
@@ -763,14 +763,26 @@ int launch_forward(const Call<T> &c, const T *input, const T *filter, T *output,
 
 // Rows of the populated-rows G matrix (conv3p_backward_sparse.hpp) that fit LDS next to the kernel's other arrays with
 // four (else three, else two) workgroups per CU; 0: use backward_kernel's dense G.
+// LDS of backward_kernel's dense G for a register-path shape (what launch_backward asks for)
+template <typename T> size_t dense_backward_lds(const Stencil<T> &st, int cin, int cout)
+{
+    const size_t nw = (size_t)st.ntap * cin * cout;
+    size_t tail = a16(nw * sizeof(T)) + a16((size_t)64 * cin * sizeof(T)) + a16((size_t)kWavesPerBlock * 192 * 4);
+    const size_t red = a16((size_t)kWavesPerBlock * cin * 64 * sizeof(T));
+    if (tail < red) tail = red;
+    return lds_common(st) + a16((size_t)st.ntap * cout * kCntStride * sizeof(T)) + a16(256 * sizeof(T)) + 256 + tail;
+}
 template <typename T> int sparse_cap(const Stencil<T> &st, int cin, int cout, size_t &lds)
 {
-    if (st.ntap > 64 || (st.ntap > 32 && cin >= 16) || cin < 1 || cout < 1 || cout > 16) return 0;   // (phase B holds the output channels in one 16-wide block; 33 .. 64 taps: the narrow layers' 64-bit tap sets)
+    // (phase B holds the output channels in one 16-wide block; 33 .. 64 taps: the narrow layers' 64-bit tap sets, 65 .. 128:
+    // 128-bit ones -- round 6: a 5 x 5 x 5 filter stays on the deterministic kernels)
+    if (st.ntap > 128 || (st.ntap > 32 && cin >= 16) || cin < 1 || cout < 1 || cout > 16) return 0;
     // Undilated stencils populate a third of a centre's taps and more (adjacent cells: 9 of 27 on the ModelNet-shaped
     // clouds, 650-850 rows per tile): their tiles would take two rounds, each walking the pair lists again
     // (measured: 3 -> 9 stride 1 at the cfg2 size 63.8 us against 49.5 us dense).  Dilated ones: 210-450 rows.
+    // (Unless the dense G does not fit LDS at all -- filters of many taps: then the rounds are the only register path.)
 #ifndef CONV3P_DEV_SPARSE_UNDILATED   // developer A/B build: the populated-rows kernel for undilated narrow layers too
-    if (cin < 16 && st.step[0] * st.step[1] * st.step[2] == 1) return 0;
+    if (cin < 16 && st.step[0] * st.step[1] * st.step[2] == 1 && dense_backward_lds<T>(st, cin, cout) <= kMaxLds) return 0;
 #endif
     const size_t fixed = sparse_fixed_lds<T>(st.maxfull, st.ntap, cin, cout) + 64;
     const size_t budgets[3] = {40960, 54608, 81920};
@@ -807,8 +819,11 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
         // (CONV3P_CACHE_SPARSE_NEIGHBOURHOODS) this kernel alone; without it BOTH kernels are launched and the slot's
         // regime word (tile_sched_kernel, from the lists just built) lets exactly one of them run: the choice needs
         // neither the caller nor a host synchronisation, at the price of one empty launch (~5 us).
-        const int cap = only_flagged == nullptr && !(CI < 16 && c.dense_hint) ? sparse_cap<T>(st, CI, CO, slds) : 0;
-        const bool by_regime = CI < 16 && !c.sparse_hint;
+        // (a filter whose dense G does not fit LDS -- more than ~60 taps at 9 output channels -- has only this kernel: no
+        // regime word, no hint can send it to the dense one)
+        const bool dense_fits = dense_backward_lds<T>(st, CI, CO) <= kMaxLds;
+        const int cap = only_flagged == nullptr && !(CI < 16 && c.dense_hint && dense_fits) ? sparse_cap<T>(st, CI, CO, slds) : 0;
+        const bool by_regime = CI < 16 && !c.sparse_hint && dense_fits;
         if (cap > 0) {
             const BlockMap bm = make_blockmap(d);
             Scope sc(K_BACKWARD, c.s);
@@ -821,10 +836,11 @@ int launch_backward(const Call<T> &c, const T *grad_out, const T *input, const T
                                    by_regime ? S.regime : static_cast<const uint32_t *>(nullptr));
             };
             if constexpr (CI < 16) {
-                if (st.ntap > 32) go(backward_sparse_kernel<T, CI, CO, true>);   // 64-bit tap sets
-                else go(backward_sparse_kernel<T, CI, CO, false>);
+                if (st.ntap > 64) go(backward_sparse_kernel<T, CI, CO, 2>);        // 128-bit tap sets
+                else if (st.ntap > 32) go(backward_sparse_kernel<T, CI, CO, 1>);   // 64-bit tap sets
+                else go(backward_sparse_kernel<T, CI, CO, 0>);
             } else {
-                go(backward_sparse_kernel<T, CI, CO, false>);
+                go(backward_sparse_kernel<T, CI, CO, 0>);
             }
             if (!by_regime) return hip_ok();
             regime = S.regime;

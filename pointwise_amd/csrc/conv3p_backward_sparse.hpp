@@ -51,7 +51,7 @@ struct __attribute__((aligned(16))) TapInfo {
 // (tap tables for 32 taps, or 64 for filters of 33 .. 64 taps: the kernel's BIG instantiation)
 template <typename T> __host__ __device__ inline size_t sparse_fixed_lds(int maxfull, int ntap, int cin, int cout)
 {
-    const size_t maxt = ntap > 32 ? 64 : 32;
+    const size_t maxt = ntap > 64 ? 128 : ntap > 32 ? 64 : 32;
     return (((size_t)3 * maxfull * 2 + 15) & ~(size_t)15) + maxt * sizeof(TapInfo) + (maxt + 32) * 4 + 256 + 64 * maxt +
            ((256 * sizeof(T) + 15) & ~(size_t)15) + (((size_t)64 * cin * sizeof(T) + 15) & ~(size_t)15) + (size_t)kWavesPerBlock * 192 * 4;
 }
@@ -64,7 +64,7 @@ template <typename T> __host__ __device__ inline size_t sparse_min_rows(int cin,
 // The pass of ONE query tile; the whole workgroup calls it.  live: the workgroup has a tile (else it only zeroes its
 // grad_filter partial); slot_idx: index of the workgroup's partial; sync: the hand-off points of a fused stack launch
 // (conv3p_stack_fused.hpp) or NoSync.
-template <typename T, int CIN, int COUT, bool BIG, class Sync>   // BIG: filters of 33 .. 64 taps (64-bit tap sets; narrow layers only)
+template <typename T, int CIN, int COUT, int BIG, class Sync>   // BIG: 1 = filters of 33 .. 64 taps (64-bit tap sets), 2 = 65 .. 128 taps (128-bit); narrow layers only
 __device__ __forceinline__ void backward_sparse_tile(
     const PointRec<T> *__restrict__ pts, const T *__restrict__ boxes, const int32_t *__restrict__ count,
     const PairEntry *__restrict__ pairs, const uint2 *__restrict__ segs, const uint2 *__restrict__ qsegs,
@@ -77,8 +77,8 @@ __device__ __forceinline__ void backward_sparse_tile(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
-    constexpr int kMaxT = BIG ? 64 : 32;                          // taps the tables hold
-    using BM = std::conditional_t<BIG, uint64_t, uint32_t>;       // set of backward taps of a centre
+    constexpr int kMaxT = BIG == 2 ? 128 : BIG ? 64 : 32;         // taps the tables hold
+    using BM = std::conditional_t<BIG == 2, unsigned __int128, std::conditional_t<BIG == 1, uint64_t, uint32_t>>;   // set of backward taps of a centre
     static_assert(!BIG || CIN < 16, "64-bit tap sets: narrow layers only (phase C of the wide ones shuffles 32-bit sets)");
     TapInfo *tapinfo = reinterpret_cast<TapInfo *>(smem + off);
     off += kMaxT * sizeof(TapInfo);
@@ -125,7 +125,12 @@ __device__ __forceinline__ void backward_sparse_tile(
     // loads that need nothing from LDS go out now, under the prologue: the tile's tap sets, its segment records (is
     // the tile's pair list complete?), this lane's centre segment and the first records of its list
     BM bm_raw = qbm[tile_id * 64 + lane];
-    if constexpr (BIG) bm_raw |= (BM)qbm_hi[tile_id * 64 + lane] << 32;
+    if constexpr (BIG >= 1) bm_raw |= (BM)qbm_hi[tile_id * 64 + lane] << 32;
+    if constexpr (BIG == 2) {   // planes 2 and 3 follow plane 1 at the planes' common stride (qbm_hi - qbm)
+        const size_t pstride = (size_t)(qbm_hi - qbm);
+        bm_raw |= (BM)qbm_hi[pstride + tile_id * 64 + lane] << 64;
+        bm_raw |= (BM)qbm_hi[2 * pstride + tile_id * 64 + lane] << 96;
+    }
     bool overflow = false;
     for (int g = 0; g < ngroups; ++g) overflow |= segs[tile_id * ngroups + g].y == kSegOverflow;
     LaneShare ls0;
@@ -162,7 +167,7 @@ __device__ __forceinline__ void backward_sparse_tile(
     auto build_rows = [&](BM bmv) {
         uint32_t base = 0, gbase = 0, nrounds = 1;
         for (int f = 0; f < st.ntap; ++f) {   // (ntap <= kMaxT: host)
-            const bool has = (bmv >> f) & 1u;
+            const bool has = (uint32_t)(bmv >> f) & 1u;
             const uint64_t m = __ballot(has);
             const uint32_t n = (uint32_t)__popcll(m);
             if (base + n > (uint32_t)cap) {
@@ -571,7 +576,7 @@ __device__ __forceinline__ void backward_sparse_tile(
         // ---- phase C: lane = centre, wave w takes the round's taps f' == w (mod 4)
         {
             for (int f = t0 + ((wave - t0) & (kWavesPerBlock - 1)); f < ((CONV3P_SP_ABLATE & 4) ? t0 : t1); f += kWavesPerBlock) {
-                const bool has = (mybm >> f) & 1u;
+                const bool has = (uint32_t)(mybm >> f) & 1u;
                 if (!__any(has)) continue;
                 const uint32_t s = has ? slot_of((uint32_t)f, lt_lane) : 0u;
                 T g[COUT];
@@ -826,7 +831,7 @@ __device__ __forceinline__ void backward_sparse_tile(
     sync.arrive();
 }
 
-template <typename T, int CIN, int COUT, bool BIG = false>
+template <typename T, int CIN, int COUT, int BIG = 0>
 // (four waves per SIMD -- four workgroups per CU -- for the models' 3- and 9-input layers; 6 and 12 inputs, SceneNN's first
 // layer, which only gets here when dilated, would spill 2 / 16 registers under that cap; so would the 64-bit tap sets of BIG)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (CIN == 3 || CIN == 9)) ? 4 : 2))) void backward_sparse_kernel(
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!BIG && (C
     int b, qt;
     const bool live = block_to_tile(bm, sched, ntiles, b, qt);   // uniform for the workgroup
     backward_sparse_tile<T, CIN, COUT, BIG>(pts, boxes, count, pairs, segs, qsegs, qbm, qbm_hi, grad_out, input, filter, st, N, ntiles, ngroups,
-                                            grad_input, partials, act, addend, cmin, ld, cap, live, b, qt, blockIdx.x, NoSync{});
+                                            grad_input, partials, act, addend, cmin, ld, cap, live, b, qt, blockIdx.x, NoSync{});   // (BIG: 0 / 1 / 2)
 }
 
 }  // namespace conv3p

@@ -458,7 +458,7 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
                                             uint32_t *__restrict__ qbm_hi = nullptr)   // ... taps 32 .. 63 (filters of 33 .. 64 taps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t bmk[128];   // backward taps met by each centre of the tile (bit f' & 31 of word [f' >> 5][centre]), see backward_sparse_kernel
+    __shared__ uint32_t bmk[256];   // backward taps met by each centre of the tile (bit f' & 31 of word [f' >> 5][centre], up to 128 taps), see backward_sparse_kernel
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
     uint32_t *cnt = reinterpret_cast<uint32_t *>(smem + off);
@@ -485,8 +485,8 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
     if (pairs != nullptr && slot_valid(cc, b)) return;   // this cloud's lists are current (uniform)
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
     for (int e = threadIdx.x; e < st.ntap * kCntStride; e += blockDim.x) cnt[e] = 0;
-    if (threadIdx.x < 128) bmk[threadIdx.x] = 0;
-    const bool want_bm = qbm != nullptr && (st.ntap <= 32 || (st.ntap <= 64 && qbm_hi != nullptr));
+    bmk[threadIdx.x] = 0;   // (256 threads)
+    const bool want_bm = qbm != nullptr && (st.ntap <= 32 || (st.ntap <= 128 && qbm_hi != nullptr));
     const uint32_t cap = cc.pairs_per_cloud;
     const uint32_t region = (uint32_t)b * cap;   // first pair slot of this cloud's region
     const PointRec<T> *cloud_pts = pts + (size_t)b * ntiles * kTile;
@@ -664,6 +664,11 @@ __device__ __forceinline__ void search_tile(const PointRec<T> *__restrict__ pts,
     if (want_bm && threadIdx.x < 64) {
         qbm[((size_t)b * ntiles + qt) * 64 + threadIdx.x] = bmk[threadIdx.x];
         if (st.ntap > 32) qbm_hi[((size_t)b * ntiles + qt) * 64 + threadIdx.x] = bmk[64 + threadIdx.x];
+        if (st.ntap > 64) {   // planes 2 and 3 (65 .. 128 taps) follow plane 1 at the planes' common stride
+            const size_t pstride = (size_t)(qbm_hi - qbm);
+            qbm_hi[pstride + ((size_t)b * ntiles + qt) * 64 + threadIdx.x] = bmk[128 + threadIdx.x];
+            qbm_hi[2 * pstride + ((size_t)b * ntiles + qt) * 64 + threadIdx.x] = bmk[192 + threadIdx.x];
+        }
     }
     // commit: the last query tile of the cloud to finish marks the slot's lists as built from the current
     // content.  Every workgroup of the cloud passed the validity check before the ticket can reach its final

@@ -174,7 +174,7 @@ __host__ __device__ inline FusedLds fused_lds(int ntap, int maxfull, int elem, i
     L.tapmap = off; off += f_a16((size_t)3 * maxfull * 2);
     L.cnt = off; off += f_a16((size_t)ntap * kCntStride * 4);
     L.cen = off; off += (size_t)64 * 12 * elem;          // per centre: lo[3], hi[3], p[3], 3 words of padding
-    L.bmk = off; off += (ntap > 32 ? 128 : 64) * 4;
+    L.bmk = off; off += (ntap > 64 ? 256 : ntap > 32 ? 128 : 64) * 4;   // one 64-word plane of backward-tap sets per 32 taps
     L.nqw = off; off += (size_t)kWavesPerBlock * 64 * 4;
     L.misc = off; off += 16;
     L.red = off; off += 6 * 8;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
     const PointRec<T> me = cloud_pts[(size_t)qt * kTile + lane];
     const float pf[3] = {(float)me.x, (float)me.y, (float)me.z};
     const bool qvalid = me.idx >= 0 && finite3(pf[0], pf[1], pf[2]);
-    const bool want_bm = job.qbm != nullptr && (st.ntap <= 32 || (st.ntap <= 64 && job.qbm_hi != nullptr));
+    const bool want_bm = job.qbm != nullptr && (st.ntap <= 32 || (st.ntap <= 128 && job.qbm_hi != nullptr));
 
     // ---- prologue: tap table, zeroed populations, the centres' exact data, extreme centres per axis
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
@@ -385,6 +385,7 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         cen[lane] = r;
         bmk[lane] = 0;
         if (st.ntap > 32) bmk[64 + lane] = 0;
+        if (st.ntap > 64) bmk[128 + lane] = bmk[192 + lane] = 0;
     } else {
         const int a = wave - 1;
         const T pa = a == 0 ? me.x : (a == 1 ? me.y : me.z);
@@ -706,6 +707,11 @@ __global__ __launch_bounds__(256) void search_fused_kernel(const PointRec<T> *__
         if (want_bm && wave == 0) {
             job.qbm[((size_t)b * ntiles + qt) * 64 + lane] = bmk[lane];
             if (st.ntap > 32) job.qbm_hi[((size_t)b * ntiles + qt) * 64 + lane] = bmk[64 + lane];
+            if (st.ntap > 64) {   // planes 2 and 3 (65 .. 128 taps) follow plane 1 at the planes' common stride
+                const size_t pstride = (size_t)(job.qbm_hi - job.qbm);
+                job.qbm_hi[pstride + ((size_t)b * ntiles + qt) * 64 + lane] = bmk[128 + lane];
+                job.qbm_hi[2 * pstride + ((size_t)b * ntiles + qt) * 64 + lane] = bmk[192 + lane];
+            }
         }
     }
     // commit: the last query tile of the cloud to finish marks the slot's lists as built from the current content

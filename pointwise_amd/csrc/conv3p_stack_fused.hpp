@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
     for (int l = 0; l < a.nl; ++l) {
         const StackBwdLayer<T> &L = a.layer[l];
         const CloudSync sy{cnt, a.base + (uint32_t)(a.ntiles * (l + 1)), true, l + 1 < a.nl};
-        backward_sparse_tile<T, H, H, false>(a.pts, a.boxes, L.count, L.pairs, L.segs, L.qsegs, L.qbm, static_cast<const uint32_t *>(nullptr),
+        backward_sparse_tile<T, H, H, 0>(a.pts, a.boxes, L.count, L.pairs, L.segs, L.qsegs, L.qbm, static_cast<const uint32_t *>(nullptr),
                                              L.grad_out, L.input, L.filter, L.st, a.N, a.ntiles, 1, L.grad_input, L.partials, 1, L.addend,
                                              static_cast<const T *>(nullptr), L.ld, L.cap, true, b, qt, blockIdx.x, sy);
         if (l == 0) check_placement(cnt, a.base, qt);

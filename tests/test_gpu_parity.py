@@ -697,6 +697,51 @@ def test_filters_of_33_to_64_taps_keep_the_populated_rows_backward(dev, ci, co, 
         assert rel_err(got[2].cpu().numpy(), rdw) <= max(tol_w, 4.0 * rel_err(rdw, r64[1]))
 
 
+@pytest.mark.parametrize("ci,co,filt,s,kind", [(9, 9, (5, 5, 5), (1, 1, 1), "modelnet"), (3, 9, (5, 5, 5), (2, 2, 2), "modelnet"),
+                                               (9, 9, (5, 4, 5), (1, 2, 1), "room"), (9, 3, (3, 5, 7), (2, 1, 1), "lattice")])
+def test_filters_of_65_to_128_taps_stay_on_the_deterministic_kernels(dev, ci, co, filt, s, kind):
+    """Filters of 65 .. 128 taps (5 x 5 x 5 = 125): the dense G of backward_kernel no longer fits LDS, and until round 5 such
+    layers took the thread-per-pair kernels with global float atomics (not reproducible).  Now: the populated-rows backward
+    with 128-bit tap sets (four planes of `qbm`), its rounds by tap ranges, whatever the hint and for undilated stencils
+    too; the forward was on the register path already.  No memset and no atomics kernel in the profile, bit-identical
+    repeats (cached, stateless), oracle parity."""
+    lib = _lib.load()
+    B, N = 2, 700
+    P, X, W, dY = make_case(kind, B, N, ci, co, filt, seed=1850)
+    ntap = filt[0] * filt[1] * filt[2]
+    assert 64 < ntap <= 128
+    cache = op.NeighborCache(B, N, torch.float32, dev, slots=1, max_taps=ntap, max_cin=ci, max_cout=co)
+    lib.conv3p_profile_reset()
+    lib.conv3p_profile_enable(1)
+    a = _both(dev, cache, P, X, W, dY, s)
+    torch.cuda.synchronize()
+    lib.conv3p_profile_enable(0)
+    seen = {}
+    for k in range(lib.conv3p_profile_kinds()):
+        n = ctypes.c_uint64(0)
+        lib.conv3p_profile_read(k, ctypes.byref(n), None)
+        seen[lib.conv3p_profile_name(k).decode()] = n.value
+    lib.conv3p_profile_reset()
+    assert seen.get("memset", 0) == 0, seen        # (the atomics kernels accumulate into zeroed outputs)
+    b = _both(dev, cache, P, X, W, dY, s)
+    c = _both(dev, None, P, X, W, dY, s)
+    d = _both(dev, None, P, X, W, dY, s)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    for u, v in zip(c, d):
+        assert torch.equal(u, v)
+    ry = oracle.forward(P, X, W, s, VOX)
+    rdx, rdw = oracle.backward(dY, P, X, W, s, VOX)
+    r64 = oracle.backward(dY.astype(np.float64), P.astype(np.float64), X.astype(np.float64), W.astype(np.float64), s, VOX)
+    tol_y, tol_w = TOL[np.dtype(np.float32)]
+    cnt = op.neighbor_count(torch.from_numpy(P).to(dev), filt, s, VOX).cpu().numpy()
+    assert np.array_equal(cnt, oracle.neighbor_count(P, filt, s, VOX))
+    for got in (a, c):
+        assert rel_err(got[0].cpu().numpy(), ry) <= tol_y
+        assert rel_err(got[1].cpu().numpy(), rdx) <= tol_y
+        assert rel_err(got[2].cpu().numpy(), rdw) <= max(tol_w, 4.0 * rel_err(rdw, r64[1]))
+
+
 def test_stack_with_cache_hints_over_changing_batches(dev):
     """What bench.py does: one Conv3pStack (neighbour cache + POINTS_UNCHANGED hints inside a step) fed a
     different batch every step must give exactly what a cache-less stack gives, step after step."""
