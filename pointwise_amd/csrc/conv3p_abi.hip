@@ -592,8 +592,10 @@ template <typename T> int launch_fused(const Call<T> &c, const FusedJobs<T> &job
     };
     if (ext3) launch(search_fused_kernel<T, true>);
     else launch(search_fused_kernel<T, false>);
+#ifndef CONV3P_DEV_NO_SCHED   // developer A/B build: no launch order at all (BlockMap order; needs a hint: no regime word either)
     if (schedule)
         hipLaunchKernelGGL(tile_sched_kernel, dim3(8, njobs), dim3(1024), 0, c.s, sjobs, d.B, d.ntiles, c.L.ngroups, bm.rounds * d.ntiles);
+#endif
     return hip_ok();
 }
 
