@@ -74,6 +74,11 @@ __device__ __forceinline__ void backward_sparse_tile(
     int cap,   // G rows (slots) the LDS allocation holds; >= 64, so every tap fits a round of its own
     bool live, int b, int qt, unsigned slot_idx, const Sync &sync)
 {
+    // (fused stack launch: the same code once per layer in one kernel -- thread-index-derived values must not stay live across
+    // the layers, see forward_tile)
+    uint32_t tid_ = threadIdx.x;
+    if constexpr (Sync::kActive) asm volatile("" : "+v"(tid_));
+    const uint32_t tid = tid_;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int16_t *tapmap = reinterpret_cast<int16_t *>(smem);
     size_t off = align16((size_t)3 * st.maxfull * 2);
@@ -93,7 +98,7 @@ __device__ __forceinline__ void backward_sparse_tile(
     const size_t nw = (size_t)st.ntap * CIN * COUT;
     T *xt = reinterpret_cast<T *>(smem + off);                    // X tile [64][CIN]
     off += align16((size_t)64 * CIN * sizeof(T));
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = tid >> 6, lane = tid & 63;
     float *soa = reinterpret_cast<float *>(smem + off) + wave * 192;
     off += align16((size_t)kWavesPerBlock * 192 * 4);
     T *G = reinterpret_cast<T *>(smem + off);                     // [cap][COUT]
@@ -116,7 +121,7 @@ __device__ __forceinline__ void backward_sparse_tile(
     DEV_SP_DECL()
     SDBG()
     build_tapmap(tapmap, st.full, st.step, st.maxfull);
-    rinv[threadIdx.x] = (T)1 / (T)(int)threadIdx.x;
+    rinv[tid] = (T)1 / (T)(int)tid;
 
     const PointRec<T> *cloud_pts = pts + (size_t)(live ? b : 0) * ntiles * kTile;
     PointRec<T> me = cloud_pts[(size_t)(live ? qt : 0) * kTile + lane];
@@ -171,7 +176,7 @@ __device__ __forceinline__ void backward_sparse_tile(
             const uint64_t m = __ballot(has);
             const uint32_t n = (uint32_t)__popcll(m);
             if (base + n > (uint32_t)cap) {
-                if (threadIdx.x == 0) rinfo[1 + nrounds] = (uint32_t)f;
+                if (tid == 0) rinfo[1 + nrounds] = (uint32_t)f;
                 ++nrounds;
                 base = 0;
             }
@@ -189,7 +194,7 @@ __device__ __forceinline__ void backward_sparse_tile(
             base += n;
             gbase += (n + 3u) & ~3u;   // (a tap's entries start 4-byte aligned: phase B reads four centres per LDS load)
         }
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             rinfo[0] = nrounds;
             rinfo[1] = 0;
             rinfo[1 + nrounds] = (uint32_t)st.ntap;
@@ -199,7 +204,7 @@ __device__ __forceinline__ void backward_sparse_tile(
     __syncthreads();
     if (!live) {   // (uniform) a workgroup past the last cloud: its grad_filter partial is summed like the others
         T *z = partials + (size_t)slot_idx * nw;
-        for (uint32_t e = threadIdx.x; e < (uint32_t)nw; e += blockDim.x) z[e] = (T)0;
+        for (uint32_t e = tid; e < (uint32_t)nw; e += blockDim.x) z[e] = (T)0;
         return;
     }
 
@@ -221,7 +226,7 @@ __device__ __forceinline__ void backward_sparse_tile(
             const int used = (int)last.base + __popc(last.mask_lo) + __popc(last.mask_hi);
             float4 *G4 = reinterpret_cast<float4 *>(G);
             const int n4 = (int)(((size_t)used * COUT * sizeof(T) + 15) / 16);
-            for (int e = threadIdx.x; e < n4; e += blockDim.x) G4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = tid; e < n4; e += blockDim.x) G4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     // ---- phase A of the wide layers (>= 16 inputs; 36 -> 13 of the scene-segmentation stack).  Four ADJACENT lanes work on
@@ -550,7 +555,7 @@ __device__ __forceinline__ void backward_sparse_tile(
                     }
             }
         } else {
-            for (int row = t0 * COUT + (int)threadIdx.x; row < t1 * COUT; row += blockDim.x) {
+            for (int row = t0 * COUT + (int)tid; row < t1 * COUT; row += blockDim.x) {
                 const int f = row / COUT, c = row - f * COUT;
                 const TapInfo ti = tapinfo[f];
                 uint64_t m = ((uint64_t)ti.mask_hi << 32) | ti.mask_lo;
@@ -704,6 +709,23 @@ __device__ __forceinline__ void backward_sparse_tile(
     };
     T dx[CIN];
     bool red_written = false;   // (uniform)
+    // The SELU-gradient epilogue needs, per output element, the caller's addend (global, by original index) and the slope at
+    // the layer's own input -- which is the X tile already in LDS.  The addend values of this thread's elements (k = wave,
+    // wave + 4, ...; centre = lane) are requested before phase C of a one-round tile, so that the epilogue does not start
+    // with two exposed gathers (round 6: reduce + store 3.9 us per wave, max 10-14, on every tile's path).
+    constexpr int kEpi = (CIN * 64 + 255) / 256;
+    constexpr bool kEarlyAddend = (CIN == 9 && COUT == 9) || CIN >= 16;   // (9 -> 3 at the 128-register cap: two spills)
+    T addv[kEpi];
+#pragma unroll
+    for (int it = 0; it < kEpi; ++it) addv[it] = (T)0;
+    const T *addend_row = addend + ((size_t)b * N + (orig_lane >= 0 ? orig_lane : 0)) * ld.add;   // (only dereferenced if addend)
+#define CONV3P_SP_LOAD_ADDEND()                                                                     \
+    if ((act & 1) && addend != nullptr) {                                                           \
+        _Pragma("unroll") for (int it = 0; it < kEpi; ++it) {                                       \
+            const int k_ = wave + kWavesPerBlock * it;                                              \
+            addv[it] = addend_row[k_ < CIN ? k_ : 0];                                               \
+        }                                                                                           \
+    }
     SDBG()
     sync.wait();   // (fused stack launch: phase A gathers other tiles' grad rows of the layer above; every path below has a
                    // workgroup barrier between here and its first gather)
@@ -731,6 +753,7 @@ __device__ __forceinline__ void backward_sparse_tile(
 #endif
         phase_B(0, st.ntap);
         SDBG()
+        if constexpr (kEarlyAddend) { CONV3P_SP_LOAD_ADDEND() }
         if constexpr (kMfmaC) {
             f32x4 acc1[4][NKC];
             zero_acc(acc1);
@@ -814,17 +837,38 @@ __device__ __forceinline__ void backward_sparse_tile(
 #pragma unroll
         for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
-        const int k = e >> 6;   // e & 63 == lane
-        T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+    if constexpr (kEarlyAddend) {
+        if (nrounds != 1) { CONV3P_SP_LOAD_ADDEND() }   // (tiles of several rounds: here)
+        __syncthreads();
 #pragma unroll
-        for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
-        if (orig_lane >= 0) {
-            const size_t rr = (size_t)b * N + orig_lane;
-            if (act & 2) sum += grad_input[rr * ld.dx + k];
-            if (act & 1) sum = (addend ? sum + addend[rr * ld.add + k] : sum) * selu_slope(input[rr * ld.in + k]);
-            grad_input[rr * ld.dx + k] = sum;
+        for (int it = 0; it < kEpi; ++it) {
+            const int k = wave + kWavesPerBlock * it;   // (element e = threadIdx.x + 256 it: k = e >> 6, centre = lane)
+            if (k < CIN) {
+                T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
+                if (orig_lane >= 0) {
+                    const size_t rr = (size_t)b * N + orig_lane;
+                    if (act & 2) sum += grad_input[rr * ld.dx + k];
+                    // (xt[lane][k] IS input[rr][k]: the X tile loaded in the prologue)
+                    if (act & 1) sum = (addend ? sum + addv[it] : sum) * selu_slope(xt[lane * CIN + k]);
+                    grad_input[rr * ld.dx + k] = sum;
+                }
+            }
+        }
+    } else {   // (the other shapes, some of them at the 128-register cap: as before)
+        __syncthreads();
+        for (int e = tid; e < CIN * 64; e += blockDim.x) {
+            const int k = e >> 6;   // e & 63 == lane
+            T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
+            if (orig_lane >= 0) {
+                const size_t rr = (size_t)b * N + orig_lane;
+                if (act & 2) sum += grad_input[rr * ld.dx + k];
+                if (act & 1) sum = (addend ? sum + addend[rr * ld.add + k] : sum) * selu_slope(input[rr * ld.in + k]);
+                grad_input[rr * ld.dx + k] = sum;
+            }
         }
     }
     DEV_SP_PRINT(CIN, COUT, wave, lane, nrounds == 1)

@@ -14,7 +14,8 @@
 //        33554432       backward_kernel: per-phase stamps (tools/bw_trace.py)
 //        134217728      forward_tile: per-phase stamps (tools/phase_trace.py, tools/fused_trace.py)
 //   -DCONV3P_SP_ABLATE=<bits>    backward_sparse_tile: 1 / 2 / 4 no phase A / B / C, 32 / 64 / 2048 gathers from L1, 256 / 512 /
-//        1024 no read-modify-write, 128 per-phase stamps
+//        1024 no read-modify-write, 128 per-phase stamps, 4096 stack_backward_kernel: per-layer spin / tile / arrive
+//        stamps, printed once at the end of the kernel (conv3p_stack_fused.hpp; tools/fused_trace.py --backward)
 //   -DCONV3P_DEV_FUSED_ABLATE=<bits>   search_fused_kernel (conv3p_search_fused.hpp)
 // Stamps are 10-ns ticks of wall_clock64() taken after an s_waitcnt(0), printed by lane 0 of every wave of every 211th
 // workgroup.

@@ -1660,6 +1660,22 @@ __global__ __launch_bounds__(256) void backward_kernel(
             T dx[CIN];
 #pragma unroll
             for (int k = 0; k < CIN; ++k) dx[k] = (T)0;
+            // (round 6) what the SELU-gradient epilogue needs of global memory -- the caller's addend and the layer's own input
+            // at this thread's elements (k = wave, wave + 4, ...; centre = lane) -- is requested now, under phase C, instead of
+            // as two exposed gathers at the start of the epilogue (the X tile holds the input rows, but `red` overwrites it)
+            constexpr int kEpi = (CIN * 64 + 255) / 256;
+            T addv[kEpi], xinv[kEpi];
+#pragma unroll
+            for (int it = 0; it < kEpi; ++it) addv[it] = xinv[it] = (T)0;
+            if (live && (act & 1)) {
+                const size_t r_ = (size_t)b * N + (me.idx >= 0 ? me.idx : 0);
+#pragma unroll
+                for (int it = 0; it < kEpi; ++it) {
+                    const int k_ = wave + kWavesPerBlock * it;
+                    xinv[it] = input[r_ * ld.in + (k_ < CIN ? k_ : 0)];
+                    if (addend != nullptr) addv[it] = addend[r_ * ld.add + (k_ < CIN ? k_ : 0)];
+                }
+            }
             // rows are taken 4 at a time per wave so that the LDS reads of a step are independent (the loop is
             // latency-bound at 2 waves per SIMD); summation order stays fixed: ascending row within a wave
             {
@@ -1689,19 +1705,23 @@ __global__ __launch_bounds__(256) void backward_kernel(
 #pragma unroll
             for (int k = 0; k < CIN; ++k) red[((size_t)wave * CIN + k) * 64 + lane] = dx[k];
             __syncthreads();
-            if (live)
-                for (int e = threadIdx.x; e < CIN * 64; e += blockDim.x) {
-                    const int k = e >> 6;   // e & 63 == lane
-                    T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+            if (live) {
 #pragma unroll
-                    for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
-                    if (me.idx >= 0) {
-                        const size_t r = (size_t)b * N + me.idx;
-                        if (act & 2) sum += grad_input[r * ld.dx + k];
-                        if (act & 1) sum = (addend ? sum + addend[r * ld.add + k] : sum) * selu_slope(input[r * ld.in + k]);
-                        grad_input[r * ld.dx + k] = sum;
+                for (int it = 0; it < kEpi; ++it) {
+                    const int k = wave + kWavesPerBlock * it;   // (element e = threadIdx.x + 256 it: k = e >> 6, centre = lane)
+                    if (k < CIN) {
+                        T sum = red[((size_t)0 * CIN + k) * 64 + lane];
+#pragma unroll
+                        for (int w = 1; w < kWavesPerBlock; ++w) sum += red[((size_t)w * CIN + k) * 64 + lane];
+                        if (me.idx >= 0) {
+                            const size_t r = (size_t)b * N + me.idx;
+                            if (act & 2) sum += grad_input[r * ld.dx + k];
+                            if (act & 1) sum = (addend ? sum + addv[it] : sum) * selu_slope(xinv[it]);
+                            grad_input[r * ld.dx + k] = sum;
+                        }
                     }
                 }
+            }
         }
         DEV_BWD_PRINT(CIN, COUT, wave, lane)
     }

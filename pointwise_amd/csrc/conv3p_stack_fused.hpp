@@ -72,8 +72,14 @@ struct CloudSync {
                          // [1] placement word, [2] error bits (1: a wait gave up, 2: the cloud's tiles did not share an XCC)
     uint32_t target;     // the counter's value once every tile of the cloud has stored the rows this layer gathers
     bool do_wait, do_arrive;
+#if CONV3P_SP_ABLATE & 4096   // developer stamps: [0] ticks spun in wait() (thread 0), [1] store drain, [2] barrier of arrive()
+    long long *dbg = nullptr;
+#endif
     __device__ __forceinline__ void wait() const
     {
+#if CONV3P_SP_ABLATE & 4096
+        const long long w0_ = wall_clock64();
+#endif
         if (do_wait && threadIdx.x == 0) {
             int spins = 0;
             while ((int32_t)(l2_atomic_add_ret(cnt, 0u) - target) < 0) {
@@ -84,12 +90,24 @@ struct CloudSync {
                 __builtin_amdgcn_s_sleep(CONV3P_SYNC_SLEEP);
             }
         }
+#if CONV3P_SP_ABLATE & 4096
+        if (dbg) dbg[0] += wall_clock64() - w0_;
+#endif
     }
     __device__ __forceinline__ void arrive() const
     {
         if (do_arrive) {
+#if CONV3P_SP_ABLATE & 4096
+            const long long a0_ = wall_clock64();
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been acknowledged by L2
+#if CONV3P_SP_ABLATE & 4096
+            const long long a1_ = wall_clock64();
+#endif
             __syncthreads();                                   // ... every wave's; and nobody reads this layer's LDS any more
+#if CONV3P_SP_ABLATE & 4096
+            if (dbg) { dbg[1] += a1_ - a0_; dbg[2] += wall_clock64() - a1_; }
+#endif
             if (threadIdx.x == 0) l2_atomic_add(cnt, 1u);
         }
     }
@@ -209,14 +227,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
         const CloudSync s0{cnt, a.base, false, true};
         s0.arrive();
     }
+#if CONV3P_SP_ABLATE & 4096
+    long long lt_[9];
+    long long dbg_[3] = {0, 0, 0};
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long ltop_ = wall_clock64();
+#endif
     for (int l = 0; l < a.nl; ++l) {
         const StackBwdLayer<T> &L = a.layer[l];
+#if CONV3P_SP_ABLATE & 4096
+        const CloudSync sy{cnt, a.base + (uint32_t)(a.ntiles * (l + 1)), true, l + 1 < a.nl, dbg_};
+#else
         const CloudSync sy{cnt, a.base + (uint32_t)(a.ntiles * (l + 1)), true, l + 1 < a.nl};
+#endif
+#if CONV3P_SP_ABLATE & 4096   // developer stamps: the whole tile pass of every layer, wait and arrive included
+        __builtin_amdgcn_s_waitcnt(0);
+        lt_[l < 7 ? l : 7] = wall_clock64();
+#endif
         backward_sparse_tile<T, H, H, 0>(a.pts, a.boxes, L.count, L.pairs, L.segs, L.qsegs, L.qbm, static_cast<const uint32_t *>(nullptr),
                                              L.grad_out, L.input, L.filter, L.st, a.N, a.ntiles, 1, L.grad_input, L.partials, 1, L.addend,
                                              static_cast<const T *>(nullptr), L.ld, L.cap, true, b, qt, blockIdx.x, sy);
         if (l == 0) check_placement(cnt, a.base, qt);
     }
+#if CONV3P_SP_ABLATE & 4096
+    __builtin_amdgcn_s_waitcnt(0);
+    lt_[a.nl < 8 ? a.nl : 8] = wall_clock64();
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x % 53) == 7)   // (10-ns ticks: top = the SELU-gradient rows + first arrive)
+        printf("fusedbwd wg %d wave %d: top %lld  layer0 %lld  layer1 %lld  layer2 %lld  spin %lld  drain %lld  arrivebar %lld\n", (int)blockIdx.x,
+               (int)(threadIdx.x >> 6), lt_[0] - ltop_, lt_[1] - lt_[0], lt_[2] - lt_[1], lt_[3] - lt_[2], dbg_[0], dbg_[1], dbg_[2]);
+#endif
 }
 
 // placement census (host, once per device): XCC id of every workgroup of a grid shaped like the fused launches
