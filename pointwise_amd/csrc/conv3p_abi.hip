@@ -309,17 +309,31 @@ inline size_t wide_scratch_bytes(const Dims &d, size_t pair_slots, bool forward_
            2 * up((size_t)d.ntap * kWideBlk * kWideBlk * 4);
 }
 
-// fp64 layers outside the register-path shapes (round 4): blocks of 16 input x 4 output channels, zero-padded, on the
-// register-path kernels <double, 16, 4> (their G matrix and transposed filter fit LDS in double) -- the op is linear
-// in the input-channel blocks and independent over the output-channel blocks -- instead of the global-atomics kernels.
-// Scratch: the block kernel's grad_filter partials, packed rows (input [B N][16], grad_out / result [B N][4] and
+// fp64 layers outside the register-path shapes (round 4): blocks of 16 input x 8 output channels, zero-padded, on the
+// register-path kernels <double, 16, 8> (their G matrix, 27 x 8 rows of 65 doubles = 112 KB, and transposed filter fit LDS
+// in double) -- the op is linear in the input-channel blocks and independent over the output-channel blocks -- instead
+// of the global-atomics kernels.  Block sizes measured in round 6 (profiles/r06_f64_blocks.txt; 32 -> 64 at the cfg2
+// size): 16 x 4 1.36 / 3.81 ms, 16 x 8 0.91 / 3.41, 16 x 16 forward 1.21, 32 x 16 forward 0.90, 32 x 4 backward 3.77.
+// Scratch: the block kernel's grad_filter partials, packed rows (input [B N][16], grad_out / result [B N][8] and
 // [B N][16]) and the packed filter block and its grad_filter block.
-constexpr int kF64Ki = 16, kF64Co = 4;
+#ifndef CONV3P_F64_FWD_KI
+#define CONV3P_F64_FWD_KI 16
+#define CONV3P_F64_FWD_CO 8
+#endif
+#ifndef CONV3P_F64_BWD_KI
+#define CONV3P_F64_BWD_KI 16
+#define CONV3P_F64_BWD_CO 8
+#endif
+constexpr int kF64FwdKi = CONV3P_F64_FWD_KI, kF64FwdCo = CONV3P_F64_FWD_CO;   // block of the forward pass
+constexpr int kF64BwdKi = CONV3P_F64_BWD_KI, kF64BwdCo = CONV3P_F64_BWD_CO;   // block of the backward pass
+constexpr int kF64Ki = kF64FwdKi > kF64BwdKi ? kF64FwdKi : kF64BwdKi;         // (scratch: sized for the larger of the two)
+constexpr int kF64Co = kF64FwdCo > kF64BwdCo ? kF64FwdCo : kF64BwdCo;
+constexpr int kF64Row = kF64Ki > kF64Co ? kF64Ki : kF64Co;
 inline bool f64_blocked_shape(int elem, int cin, int cout) { return elem == 8 && cin >= 1 && cout >= 1 && !small_shape(elem, cin, cout); }
 inline size_t f64_blocked_bytes(const Dims &d)
 {
     const size_t rows = (size_t)d.B * d.N, nwb = (size_t)d.ntap * kF64Ki * kF64Co;
-    return up((size_t)grid_of(make_blockmap(d)) * nwb * 8) + 3 * up(rows * kF64Ki * 8) + 2 * up(nwb * 8);
+    return up((size_t)grid_of(make_blockmap(d)) * nwb * 8) + 3 * up(rows * kF64Row * 8) + 2 * up(nwb * 8);
 }
 
 // ppp: pair slots per point of the buffer the call runs in (a cache may be configured with fewer than the default)
@@ -1229,8 +1243,8 @@ int wide_backward(const Call<float> &c, const float *grad_out, const float *inpu
 // ----------------------------------------------------------------------------- fp64 layers outside the register-path shapes
 struct F64Scratch {
     double *parts;          // the block kernel's grad_filter partials
-    double *xp, *yp, *zp;   // packed rows: input block [B N][16], grad_out block / forward result [B N][4], grad_input block [B N][16]
-    double *wp, *dwp;       // [ntap][16][4] filter block, its grad_filter block
+    double *xp, *yp, *zp;   // packed rows: input block [B N][16], grad_out block / forward result [B N][8], grad_input block [B N][16]
+    double *wp, *dwp;       // [ntap][16][8] filter block, its grad_filter block
 };
 inline F64Scratch carve_f64(const Call<double> &c)
 {
@@ -1239,9 +1253,9 @@ inline F64Scratch carve_f64(const Call<double> &c)
     char *p = reinterpret_cast<char *>(c.L.partials);
     F64Scratch w{};
     w.parts = reinterpret_cast<double *>(p); p += up((size_t)grid_of(make_blockmap(d)) * nwb * 8);
-    w.xp = reinterpret_cast<double *>(p); p += up(rows * kF64Ki * 8);
-    w.yp = reinterpret_cast<double *>(p); p += up(rows * kF64Ki * 8);
-    w.zp = reinterpret_cast<double *>(p); p += up(rows * kF64Ki * 8);
+    w.xp = reinterpret_cast<double *>(p); p += up(rows * kF64Row * 8);
+    w.yp = reinterpret_cast<double *>(p); p += up(rows * kF64Row * 8);
+    w.zp = reinterpret_cast<double *>(p); p += up(rows * kF64Row * 8);
     w.wp = reinterpret_cast<double *>(p); p += up(nwb * 8);
     w.dwp = reinterpret_cast<double *>(p);
     return w;
@@ -1252,24 +1266,24 @@ inline int f64_pack_rows(const Call<double> &c, const double *src, int ld_s, dou
     hipLaunchKernelGGL(copy_cols_kernel<double>, dim3(grid_1d(rows * cols)), dim3(256), 0, c.s, src, dst, rows, cols, ld_s, ldp);
     return CONV3P_OK;
 }
-inline int f64_pack_filter(const Call<double> &c, const double *filter, int k0, int kw, int c0, int cw, double *wp)
+inline int f64_pack_filter(const Call<double> &c, const double *filter, int k0, int kw, int c0, int cw, double *wp, int bki, int bco)
 {
     const Dims &d = c.d;
-    if (kw < kF64Ki || cw < kF64Co) TRY(zero_async(wp, (size_t)d.ntap * kF64Ki * kF64Co * 8, c.s));
+    if (kw < bki || cw < bco) TRY(zero_async(wp, (size_t)d.ntap * bki * bco * 8, c.s));
     hipLaunchKernelGGL(copy_block_kernel<double>, dim3(grid_1d((size_t)d.ntap * kw * cw)), dim3(256), 0, c.s,
                        filter + (size_t)k0 * d.Cout + c0, wp, d.ntap, kw, cw, (size_t)d.Cin * d.Cout, d.Cout,
-                       (size_t)kF64Ki * kF64Co, kF64Co);
+                       (size_t)bki * bco, bco);
     return CONV3P_OK;
 }
-inline Call<double> f64_block_call(const Call<double> &c)
+inline Call<double> f64_block_call(const Call<double> &c, int bki, int bco)
 {
     Call<double> cp = c;
-    cp.d.Cin = kF64Ki;
-    cp.d.Cout = kF64Co;
+    cp.d.Cin = bki;
+    cp.d.Cout = bco;
     cp.act = false;
     cp.accum = false;
     cp.addend = nullptr;
-    set_ld(cp, nullptr, kF64Ki, kF64Co);
+    set_ld(cp, nullptr, bki, bco);
     return cp;
 }
 
@@ -1279,20 +1293,20 @@ int f64_blocked_forward(const Call<double> &c, const double *input, const double
     const Dims &d = c.d;
     const size_t rows = (size_t)d.B * d.N;
     const F64Scratch w = carve_f64(c);
-    const Call<double> cp = f64_block_call(c);
-    for (int k0 = 0; k0 < d.Cin; k0 += kF64Ki) {
-        const int kw = d.Cin - k0 < kF64Ki ? d.Cin - k0 : kF64Ki;
-        TRY(f64_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kF64Ki));
-        for (int c0 = 0; c0 < d.Cout; c0 += kF64Co) {
-            const int cw = d.Cout - c0 < kF64Co ? d.Cout - c0 : kF64Co;
-            TRY(f64_pack_filter(c, filter, k0, kw, c0, cw, w.wp));
-            TRY((launch_forward<double, kF64Ki, kF64Co>(cp, w.xp, w.wp, w.yp)));
+    const Call<double> cp = f64_block_call(c, kF64FwdKi, kF64FwdCo);
+    for (int k0 = 0; k0 < d.Cin; k0 += kF64FwdKi) {
+        const int kw = d.Cin - k0 < kF64FwdKi ? d.Cin - k0 : kF64FwdKi;
+        TRY(f64_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kF64FwdKi));
+        for (int c0 = 0; c0 < d.Cout; c0 += kF64FwdCo) {
+            const int cw = d.Cout - c0 < kF64FwdCo ? d.Cout - c0 : kF64FwdCo;
+            TRY(f64_pack_filter(c, filter, k0, kw, c0, cw, w.wp, kF64FwdKi, kF64FwdCo));
+            TRY((launch_forward<double, kF64FwdKi, kF64FwdCo>(cp, w.xp, w.wp, w.yp)));
             if (k0 == 0)
                 hipLaunchKernelGGL(copy_cols_kernel<double>, dim3(grid_1d(rows * cw)), dim3(256), 0, c.s, w.yp, output + c0, rows, cw,
-                                   kF64Co, d.Cout);
+                                   kF64FwdCo, d.Cout);
             else
                 hipLaunchKernelGGL(add_cols_kernel<double>, dim3(grid_1d(rows * cw)), dim3(256), 0, c.s, w.yp, output + c0, rows, cw,
-                                   kF64Co, d.Cout);
+                                   kF64FwdCo, d.Cout);
         }
     }
     return hip_ok();
@@ -1304,18 +1318,18 @@ int f64_blocked_backward(const Call<double> &c, const double *grad_out, const do
                          double *grad_input, double *grad_filter)
 {
     const Dims &d = c.d;
-    const size_t rows = (size_t)d.B * d.N, nwb = (size_t)d.ntap * kF64Ki * kF64Co;
+    const size_t rows = (size_t)d.B * d.N, nwb = (size_t)d.ntap * kF64BwdKi * kF64BwdCo;
     const int nslots = (int)grid_of(make_blockmap(d));
     const F64Scratch w = carve_f64(c);
-    const Call<double> cp = f64_block_call(c);
-    for (int k0 = 0; k0 < d.Cin; k0 += kF64Ki) {
-        const int kw = d.Cin - k0 < kF64Ki ? d.Cin - k0 : kF64Ki;
-        TRY(f64_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kF64Ki));
-        for (int c0 = 0; c0 < d.Cout; c0 += kF64Co) {
-            const int cw = d.Cout - c0 < kF64Co ? d.Cout - c0 : kF64Co;
-            TRY(f64_pack_rows(c, grad_out + c0, d.Cout, w.yp, rows, cw, kF64Co));
-            TRY(f64_pack_filter(c, filter, k0, kw, c0, cw, w.wp));
-            TRY((launch_backward<double, kF64Ki, kF64Co>(cp, w.yp, w.xp, w.wp, w.zp, w.parts)));
+    const Call<double> cp = f64_block_call(c, kF64BwdKi, kF64BwdCo);
+    for (int k0 = 0; k0 < d.Cin; k0 += kF64BwdKi) {
+        const int kw = d.Cin - k0 < kF64BwdKi ? d.Cin - k0 : kF64BwdKi;
+        TRY(f64_pack_rows(c, input + k0, d.Cin, w.xp, rows, kw, kF64BwdKi));
+        for (int c0 = 0; c0 < d.Cout; c0 += kF64BwdCo) {
+            const int cw = d.Cout - c0 < kF64BwdCo ? d.Cout - c0 : kF64BwdCo;
+            TRY(f64_pack_rows(c, grad_out + c0, d.Cout, w.yp, rows, cw, kF64BwdCo));
+            TRY(f64_pack_filter(c, filter, k0, kw, c0, cw, w.wp, kF64BwdKi, kF64BwdCo));
+            TRY((launch_backward<double, kF64BwdKi, kF64BwdCo>(cp, w.yp, w.xp, w.wp, w.zp, w.parts)));
             {
                 Scope sc(K_REDUCE, c.s);
                 hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3((unsigned)((nwb + kReduceW - 1) / kReduceW)), dim3(1024), 0, c.s, w.parts,
@@ -1323,12 +1337,12 @@ int f64_blocked_backward(const Call<double> &c, const double *grad_out, const do
             }
             if (c0 == 0)
                 hipLaunchKernelGGL(copy_cols_kernel<double>, dim3(grid_1d(rows * kw)), dim3(256), 0, c.s, w.zp, grad_input + k0, rows,
-                                   kw, kF64Ki, d.Cin);
+                                   kw, kF64BwdKi, d.Cin);
             else
                 hipLaunchKernelGGL(add_cols_kernel<double>, dim3(grid_1d(rows * kw)), dim3(256), 0, c.s, w.zp, grad_input + k0, rows,
-                                   kw, kF64Ki, d.Cin);
+                                   kw, kF64BwdKi, d.Cin);
             hipLaunchKernelGGL(copy_block_kernel<double>, dim3(grid_1d((size_t)d.ntap * kw * cw)), dim3(256), 0, c.s, w.dwp,
-                               grad_filter + (size_t)k0 * d.Cout + c0, d.ntap, kw, cw, (size_t)kF64Ki * kF64Co, kF64Co,
+                               grad_filter + (size_t)k0 * d.Cout + c0, d.ntap, kw, cw, (size_t)kF64BwdKi * kF64BwdCo, kF64BwdCo,
                                (size_t)d.Cin * d.Cout, d.Cout);
         }
     }
@@ -1595,7 +1609,7 @@ int forward_impl(const T *points, const T *input, const T *filter, const int32_t
         }
     }
     if constexpr (sizeof(T) == 8) {
-        if (c.f64_scratch_ok && !c.strided) {   // fp64 outside the register-path shapes: 16 x 4 channel blocks on <double, 16, 4>
+        if (c.f64_scratch_ok && !c.strided) {   // fp64 outside the register-path shapes: 16 x 8 channel blocks on <double, 16, 8>
             const int rc = f64_blocked_forward(c, input, filter, output);
             if (rc != CONV3P_ERR_UNSUPPORTED) return rc != CONV3P_OK || !act ? rc : selu_impl<T>(output, output, out_elems, stream);
         }

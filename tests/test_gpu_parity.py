@@ -821,8 +821,8 @@ def test_more_than_256_channels_run_as_blocks_on_the_matrix_core_path(dev, ci, c
 @pytest.mark.parametrize("ci,co,N", [(32, 64, 2048), (5, 7, 500), (17, 3, 300), (40, 9, 700)])
 def test_fp64_outside_the_register_path_shapes_runs_as_blocks(dev, ci, co, N):
     """Round-3 verdict, item 7 (fp64 half): double precision is registered for every shape
-    (tf_conv3p_atrous.cpp:511-517, :722-728).  Shapes outside the register-path list run as blocks of 16 input x 4 output
-    channels (zero-padded) on the register-path kernels <double, 16, 4> -- fixed summation order -- instead of the
+    (tf_conv3p_atrous.cpp:511-517, :722-728).  Shapes outside the register-path list run as blocks of 16 input x 8 output
+    channels (zero-padded) on the register-path kernels <double, 16, 8> -- fixed summation order -- instead of the
     global-atomics kernels: against the float64 oracle, cached == stateless bit for bit, reproducible."""
     B = 1 if N > 1000 else 2
     P = synth.room_like(B, N, 1190, extent=(1.0, 1.0, 1.5)) if N <= 1000 else synth.modelnet_like(B, N, seed=1190)
@@ -1274,7 +1274,7 @@ def test_deep_channel_path_forgets_the_non_finite_mark_of_an_earlier_call(dev):
 @pytest.mark.parametrize("ci,co,dt", [(300, 70, np.float32), (17, 3, np.float64), (40, 9, np.float64)])
 def test_blocked_paths_non_finite_values_and_pair_buffer_overflow(dev, ci, co, dt):
     """The channel-blocked paths of round 4 (more than 256 channels on the matrix-core kernels, fp64 outside the
-    register-path shapes on <double, 16, 4>): Inf / NaN inputs land on exactly the outputs they reach in the reference
+    register-path shapes on <double, 16, 8>): Inf / NaN inputs land on exactly the outputs they reach in the reference
     (zero padding of the blocks must not turn them into extra NaNs), and a cache whose pair buffer overflows still gives
     the reference's results."""
     B, N = 2, 300
